@@ -1,0 +1,113 @@
+/*
+ * rt_scene.h -- C view of the host-side mirror of the reference crate's scene API.
+ *
+ * The reference is a Rust binary crate; where no Rust toolchain exists the C++ classes of
+ * ray-tracer_amd/host/rt.hpp stand in for its public modules, and these flat functions expose
+ * them to C, ctypes and the tests.  Each function names the Rust item it mirrors (paths
+ * relative to the reference checkout).  Functions returning int give 0 on success and 1 when
+ * the reference would have panicked; rt_last_panic() holds the message.  Everything that
+ * renders goes to the GPU through include/rtx.h.
+ */
+#ifndef RT_SCENE_H
+#define RT_SCENE_H
+
+#include <stdint.h>
+
+#include "rtx.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* scalar material fields for rt_object_set_scalar (src/surfaces/materials.rs:4-15) */
+enum {
+    RT_AMBIENT = 0, RT_DIFFUSE = 1, RT_SPECULAR = 2, RT_SHININESS = 3,
+    RT_REFLECTIVE = 4, RT_TRANSPARENCY = 5, RT_REFRACTIVE_INDEX = 6
+};
+
+typedef struct rt_object rt_object;
+typedef struct rt_world rt_world;
+typedef struct rt_camera rt_camera;
+
+const char *rt_last_panic(void);
+
+/* src/matrices/transformations.rs:3-77, src/matrices/matrix4.rs:44-193; 4x4 row-major */
+void rt_identity(double *out);
+void rt_translation(double x, double y, double z, double *out);
+void rt_scaling(double x, double y, double z, double *out);
+void rt_rotation_x(double rad, double *out);
+void rt_rotation_y(double rad, double *out);
+void rt_rotation_z(double rad, double *out);
+void rt_shearing(double xy, double xz, double yx, double yz, double zx, double zy, double *out);
+void rt_mat4_mul(const double *a, const double *b, double *out);
+void rt_mat4_transpose(const double *a, double *out);
+double rt_mat4_determinant(const double *a);
+int rt_mat4_invert(const double *a, double *out);
+void rt_mat4_mul_tuple(const double *m, const double *tup4, double *out4);
+int rt_view_transform(const double *from3, const double *to3, const double *up3, double *out);
+
+/* src/shapes/objects.rs:36-52 and the constructors of spheres.rs .. cones.rs */
+rt_object *rt_object_new(int shape, double ymin, double ymax, int closed);
+rt_object *rt_glass_sphere(void); /* src/shapes/spheres.rs:7-19 */
+rt_object *rt_object_clone(const rt_object *o);
+void rt_object_free(rt_object *o);
+int rt_object_set_transform(rt_object *o, const double *m16);                /* objects.rs:211-215 */
+int rt_object_set_transformation_list(rt_object *o, int index, double x);    /* objects.rs:217-220 */
+int rt_object_transform_op(rt_object *o, int slot, double x);                /* traits.rs:46-98 */
+void rt_object_set_color(rt_object *o, double r, double g, double b);        /* objects.rs:115-118 */
+void rt_object_set_scalar(rt_object *o, int field, double value);            /* objects.rs:120-163 */
+void rt_object_set_casts_shadow(rt_object *o, int casts);                    /* objects.rs:165-168 */
+void rt_object_set_pattern(rt_object *o, int type, const double *c1, const double *c2); /* objects.rs:140-143 */
+int rt_object_set_pattern_transform(rt_object *o, const double *m16);        /* objects.rs:145-148 */
+void rt_object_get_matrices(const rt_object *o, double *transform, double *inverse, double *inverse_t);
+void rt_object_get_pattern_inverse(const rt_object *o, double *inverse);
+int rt_object_equal(const rt_object *a, const rt_object *b);                 /* derived PartialEq, objects.rs:3 */
+
+/* src/scenes/world.rs:11-96 */
+rt_world *rt_world_new(void);
+rt_world *rt_world_default(void);
+void rt_world_free(rt_world *w);
+int rt_world_add_object(rt_world *w, const rt_object *o);
+void rt_world_add_light(rt_world *w, const double *pos3, const double *intensity3);
+void rt_world_clear_lights(rt_world *w);
+int rt_world_n_objects(const rt_world *w);
+rt_object *rt_world_object(rt_world *w, int index);
+/* World::color_at on the GPU for n rays (world.rs:136-144); counters2[0] += color_at calls,
+ * counters2[1] += is_shadowed calls */
+int rt_world_color_at_batch(const rt_world *w, const double *rays6, uint64_t n, uint32_t remaining, int precision,
+                            double *out_rgb, uint64_t *counters2);
+/* intermediate results of the f64 path for n rays, see rtx_probe_rays */
+int rt_world_probe(const rt_world *w, const double *rays6, uint64_t n, rtx_probe *out);
+/* the flattened arrays handed to rtx_scene_upload; field is one of RT_FLAT_*; returns the
+ * number of values written (or needed when out is NULL) */
+enum {
+    RT_FLAT_INVERSE = 0, RT_FLAT_INVERSE_T = 1, RT_FLAT_PATTERN_INVERSE = 2, RT_FLAT_COLOR = 3,
+    RT_FLAT_MATERIAL = 4, /* ambient, diffuse, specular, shininess, reflective, transparency, refractive_index per object */
+    RT_FLAT_YRANGE = 5,   /* ymin, ymax per object */
+    RT_FLAT_TAGS = 6,     /* shape, closed, casts_shadow, pattern_type, eq_class per object */
+    RT_FLAT_LIGHTS = 7,   /* position xyz, intensity rgb per light */
+    RT_FLAT_PATTERN_COLORS = 8 /* color1 rgb, color2 rgb per object */
+};
+int64_t rt_world_flat(const rt_world *w, int field, double *out, int64_t cap);
+
+/* src/scenes/camera.rs */
+rt_camera *rt_camera_new(uint64_t hsize, uint64_t vsize, double fov);         /* camera.rs:18-37 */
+rt_camera *rt_camera_new_preview(const rt_camera *c);                         /* camera.rs:39-55 */
+void rt_camera_free(rt_camera *c);
+int rt_camera_set_transform(rt_camera *c, const double *m16);                 /* camera.rs:101-105 */
+int rt_camera_set_view(rt_camera *c, const double *from3, const double *to3, const double *up3); /* camera.rs:123-145 */
+void rt_camera_get(const rt_camera *c, uint64_t *hsize, uint64_t *vsize, double *pixel_size, double *half_width,
+                   double *half_height, double *inverse16);
+int rt_camera_ray_for_pixel(const rt_camera *c, uint64_t x, uint64_t y, double *out_ray6); /* camera.rs:147-158 */
+/* Camera::render / parallel_render / preview_parallel_render (camera.rs:160-222) for rows
+ * [row_begin, row_end) into a buffer holding those rows only */
+int rt_camera_render_rows(const rt_camera *c, const rt_world *w, uint32_t depth, int precision, uint64_t row_begin,
+                          uint64_t row_end, double *out_rgb, rtx_stats *stats);
+/* Camera::parallel_render with the pixel tracker (camera.rs:172-201): *tracker is stored
+ * with the number of finished pixels as the frame progresses */
+int rt_camera_parallel_render(const rt_camera *c, const rt_world *w, double *out_rgb, uint64_t *tracker, rtx_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,184 @@
+/*
+ * rtx.h -- C ABI of the MI355X render loop for malloc-man/ray-tracer.
+ *
+ * This is the boundary a Rust `extern "C"` block (or any FFI) binds.  The reference has no
+ * FFI surface of its own; each entry point below names the Rust item whose body it replaces
+ * (paths relative to the reference checkout).  Plain pointers and sizes only.
+ *
+ * Conventions
+ *  - every call returns 0 on success; non-zero means "the reference would have panicked or
+ *    the device failed" and rtx_last_error() holds the message for the calling thread;
+ *  - the caller owns every input array and every output buffer; rtx_scene_upload copies
+ *    what it needs, so inputs may be freed as soon as it returns;
+ *  - a context may be shared by several host threads; concurrent render calls on one
+ *    context run on separate HIP streams with separate scratch memory;
+ *  - there is no CPU fallback: without a gfx950 device every call fails loudly.
+ */
+#ifndef RTX_H
+#define RTX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTX_OK 0
+#define RTX_ERR_INVALID 1   /* bad argument / unsupported scene (the reference would panic) */
+#define RTX_ERR_DEVICE 2    /* HIP error, no device, out of memory */
+
+/* src/shapes/objects.rs:14-20 (enum Shape) */
+enum { RTX_SPHERE = 0, RTX_PLANE = 1, RTX_CUBE = 2, RTX_CYLINDER = 3, RTX_CONE = 4 };
+/* src/surfaces/patterns.rs:13-20 (enum PatternType) */
+enum { RTX_SOLID = 0, RTX_STRIPE = 1, RTX_GRADIENT = 2, RTX_RING = 3, RTX_CHECKER3D = 4, RTX_TEST = 5 };
+/* precision of the render arithmetic */
+enum { RTX_F64 = 0, RTX_F32 = 1 };
+
+typedef struct rtx_context rtx_context;
+typedef struct rtx_scene rtx_scene;
+
+/*
+ * Flattened World (src/scenes/world.rs:6-9): one entry per Object in World.objects order,
+ * which is also the tie-break order among equal t (stable sort, world.rs:98-107).
+ * Matrices are 4x4 row-major doubles exactly as cached by the Object
+ * (src/shapes/objects.rs:4-11, 211-215) and Pattern (src/surfaces/patterns.rs:4-10).
+ */
+typedef struct rtx_scene_desc {
+    uint32_t n_objects;
+    const uint8_t *shape_type;          /* [n] RTX_SPHERE.. */
+    const double *inverse;              /* [n][16] Object.inverse_transform */
+    const double *inverse_transposed;   /* [n][16] Object.inverse_transform_transposed */
+    const double *ymin;                 /* [n] Cylinder/Cone min (ignored otherwise) */
+    const double *ymax;                 /* [n] Cylinder/Cone max */
+    const uint8_t *closed;              /* [n] Cylinder/Cone closed */
+    /* Material, src/surfaces/materials.rs:4-15 */
+    const double *color;                /* [n][3] */
+    const double *ambient;              /* [n] */
+    const double *diffuse;              /* [n] */
+    const double *specular;             /* [n] */
+    const double *shininess;            /* [n] */
+    const double *reflective;           /* [n] */
+    const double *transparency;         /* [n] */
+    const double *refractive_index;     /* [n] */
+    const uint8_t *casts_shadow;        /* [n] */
+    /* Pattern, src/surfaces/patterns.rs:4-20 */
+    const uint8_t *pattern_type;        /* [n] RTX_SOLID.. */
+    const double *pattern_inverse;      /* [n][16] Pattern.inverse_transform */
+    const double *pattern_color1;       /* [n][3] */
+    const double *pattern_color2;       /* [n][3] */
+    /* Object value-equality classes (derived PartialEq, objects.rs:3): objects that compare
+     * equal alias each other in the refraction container list (world.rs:253-285).
+     * NULL = every object is its own class. */
+    const uint32_t *eq_class;           /* [n] or NULL */
+    /* Lights, src/scenes/lights.rs:4-8.  Only lights[0] is used for shading, as in the
+     * reference (world.rs:123,147); the rest are accepted and ignored. */
+    uint32_t n_lights;
+    const double *light_position;       /* [n_lights][3] */
+    const double *light_intensity;      /* [n_lights][3] */
+} rtx_scene_desc;
+
+/* The Camera fields ray_for_pixel reads (src/scenes/camera.rs:5-15, 147-158). */
+typedef struct rtx_camera_desc {
+    uint32_t hsize, vsize;
+    double inverse_transform[16];
+    double pixel_size, half_width, half_height;
+} rtx_camera_desc;
+
+/* Ray and kernel accounting for one call. */
+typedef struct rtx_stats {
+    uint64_t color_rays;      /* World::color_at invocations (primary + reflection + refraction) */
+    uint64_t shadow_rays;     /* World::is_shadowed invocations (one per shaded hit) */
+    uint64_t rays_per_level[8]; /* color_at invocations by recursion level (0 = primary) */
+    double kernel_ms;         /* device time of the render kernels (HIP events on the call's stream) */
+    double primary_kernel_ms; /* device time of the primary-ray kernel alone */
+    double total_ms;          /* host wall time of the call, copies included */
+    uint32_t n_launches;      /* kernels launched */
+    uint32_t n_chunks;        /* row chunks the frame was split into to bound queue memory */
+} rtx_stats;
+
+/* Invoked from the calling thread after each finished row chunk with the number of pixels
+ * done so far; stands in for the Arc<AtomicUsize> tracker of
+ * Camera::parallel_render (src/scenes/camera.rs:173,192). */
+typedef void (*rtx_progress_fn)(uint64_t pixels_done, void *user);
+
+/* Message of the last failed call on this thread. */
+const char *rtx_last_error(void);
+
+/* One context per GPU.  device_id < 0 selects the current HIP device. */
+int rtx_context_create(int device_id, rtx_context **out);
+void rtx_context_destroy(rtx_context *ctx);
+/* Upper bound in bytes for the secondary-ray queues of one render call (default 8 GiB);
+ * frames that could exceed it are rendered in row chunks. */
+int rtx_context_set_workspace_limit(rtx_context *ctx, size_t bytes);
+
+/* Replaces the World a render borrows (src/scenes/world.rs:6-9): validates, repacks and
+ * copies the scene to the device.  Fails (as the reference panics, world.rs:123,147) when
+ * there are objects but no light. */
+int rtx_scene_upload(rtx_context *ctx, const rtx_scene_desc *desc, rtx_scene **out);
+void rtx_scene_destroy(rtx_scene *scene);
+
+/*
+ * Replaces the body of Camera::parallel_render (src/scenes/camera.rs:172-201, max_depth 5),
+ * Camera::preview_parallel_render (camera.rs:203-222, max_depth 2) and Camera::render
+ * (camera.rs:160-170, max_depth 5): every pixel (x, y) of rows [row_begin, row_end) gets
+ * World::color_at(ray_for_pixel(x, y), max_depth).
+ * out_rgb is a host buffer for those rows only: (row_end-row_begin)*hsize*3 values, row-major,
+ * pixel (x, y) at 3*((y-row_begin)*hsize + x) (Canvas.pixels order, src/scenes/canvas.rs:32-34);
+ * double for RTX_F64, float for RTX_F32; values are not clamped.
+ */
+int rtx_render(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_desc *camera, uint32_t max_depth,
+               int precision, uint32_t row_begin, uint32_t row_end, void *out_rgb, size_t out_bytes,
+               rtx_progress_fn progress, void *user, rtx_stats *stats);
+
+/*
+ * Same as rtx_render with the output left in device memory (d_out_rgb is a device pointer
+ * with room for the same number of values).  `stream` is a hipStream_t (NULL = the context's
+ * own stream); the call returns once the kernels are enqueued unless stats is non-NULL, in
+ * which case it waits for them and fills stats.
+ */
+int rtx_render_device(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_desc *camera, uint32_t max_depth,
+                      int precision, uint32_t row_begin, uint32_t row_end, void *d_out_rgb, size_t out_bytes,
+                      void *stream, rtx_stats *stats);
+
+/*
+ * Batch form of World::color_at (src/scenes/world.rs:136-144): rays is n x 6 doubles
+ * (origin xyz, direction xyz), out_rgb is n x 3 doubles (filled from the f32 result when
+ * precision is RTX_F32).
+ */
+int rtx_trace_rays(rtx_context *ctx, const rtx_scene *scene, const double *rays, size_t n, uint32_t max_depth,
+                   int precision, double *out_rgb, rtx_stats *stats);
+
+/*
+ * Per-ray view of the intermediate results of the f64 path, for parity tests against
+ * intersect_world / hit_world / prepare_computations / is_shadowed / lighting
+ * (src/scenes/world.rs:98-158, 242-287; src/scenes/lights.rs:43-78).
+ */
+typedef struct rtx_probe {
+    double t;              /* hit t, or -1 when there is no hit */
+    double point[3], normalv[3], over_point[3], under_point[3], reflectv[3];
+    double n1, n2;
+    double lighting[3];    /* lighting() term of shade_hit */
+    int32_t object;        /* index of the hit object, -1 on a miss */
+    int32_t inside;
+    int32_t shadowed;
+    int32_t pad;
+} rtx_probe;
+int rtx_probe_rays(rtx_context *ctx, const rtx_scene *scene, const double *rays, size_t n, rtx_probe *out);
+
+/* Primary rays exactly as the render kernel generates them (src/scenes/camera.rs:147-158):
+ * out is n x 6 doubles for pixels [first_pixel, first_pixel + n) in row-major order. */
+int rtx_generate_rays(rtx_context *ctx, const rtx_camera_desc *camera, uint64_t first_pixel, size_t n, double *out);
+
+/* (c * 255.999) as u8 per channel on the device (src/scenes/canvas.rs:84-86, 98-101):
+ * d_rgb holds n_values doubles (or floats for RTX_F32) in device memory, d_out n_values bytes. */
+int rtx_quantize_u8_device(rtx_context *ctx, const void *d_rgb, int precision, size_t n_values, uint8_t *d_out,
+                           void *stream);
+
+/* Device properties the benchmark reports. */
+int rtx_device_info(rtx_context *ctx, char *name, size_t name_bytes, int *compute_units, int *clock_mhz);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

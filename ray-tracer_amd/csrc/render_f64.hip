@@ -1,0 +1,56 @@
+// render_f64.hip -- the f64 parity path.  Build with -ffp-contract=off: the reference is
+// Rust, whose f64 arithmetic never fuses a multiply with an add, and one differing ulp in a
+// hit distance can flip a pattern cell, a shadow test or a `t >= 0` decision.
+#include "rt_kernels.h"
+
+#if defined(__FP_FAST_FMA) || defined(__FAST_MATH__)
+#error "render_f64.hip must be compiled with -ffp-contract=off and without fast-math"
+#endif
+
+namespace rtx {
+
+// One color_at node per ray with every intermediate kept: the parity tests compare these
+// with intersect_world / prepare_computations / is_shadowed / lighting of the oracle.
+template <uint32_t SF>
+__global__ void __launch_bounds__(kBlock)
+k_probe(SceneDev<double> S, const double *__restrict__ rays, uint32_t n, rtx_probe *__restrict__ out)
+{
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < n; k += stride) {
+        const double *r = rays + (size_t)k * 6;
+        V3<double> ro = { r[0], r[1], r[2] }, rd = { r[3], r[4], r[5] };
+        Node<double> nd = trace_node<double, SF>(S, ro, rd, 5u);
+        rtx_probe p;
+        __builtin_memset(&p, 0, sizeof p);
+        p.t = -1.0;
+        p.object = -1;
+        if (nd.hit) {
+            p.t = nd.t;
+            p.object = (int32_t)nd.obj;
+            p.point[0] = nd.point.x; p.point[1] = nd.point.y; p.point[2] = nd.point.z;
+            p.normalv[0] = nd.normalv.x; p.normalv[1] = nd.normalv.y; p.normalv[2] = nd.normalv.z;
+            p.over_point[0] = nd.over_point.x; p.over_point[1] = nd.over_point.y; p.over_point[2] = nd.over_point.z;
+            p.under_point[0] = nd.under_point.x; p.under_point[1] = nd.under_point.y; p.under_point[2] = nd.under_point.z;
+            p.reflectv[0] = nd.reflectv.x; p.reflectv[1] = nd.reflectv.y; p.reflectv[2] = nd.reflectv.z;
+            p.n1 = nd.n1; p.n2 = nd.n2;
+            p.lighting[0] = nd.lighting.x; p.lighting[1] = nd.lighting.y; p.lighting[2] = nd.lighting.z;
+            p.inside = nd.inside ? 1 : 0;
+            p.shadowed = nd.shadowed ? 1 : 0;
+        }
+        out[k] = p;
+    }
+}
+
+hipError_t launch_probe(uint32_t sf, uint32_t grid, hipStream_t stream, const SceneDev<double> &scene,
+                        const double *rays, uint32_t n, rtx_probe *out)
+{
+#define RTX_CALL(SFV) \
+    hipLaunchKernelGGL((k_probe<SFV | SF_PATTERN>), dim3(grid), dim3(kBlock), 0, stream, scene, rays, n, out)
+    RTX_SF_SWITCH(sf, RTX_CALL)
+#undef RTX_CALL
+    return hipGetLastError();
+}
+
+template struct Launch<double>;
+
+}  // namespace rtx

@@ -1,0 +1,259 @@
+// rt_kernels.h -- the render kernels and their launchers, templated on the scalar type.
+//
+// Kernel map (the reference's recursion, src/scenes/world.rs:121-190, unrolled by level):
+//   k_primary  one pixel per lane: ray_for_pixel -> closest hit over the object table ->
+//              shadow ray -> Phong; stores the pixel's own lighting term and appends the
+//              reflection / refraction rays it spawns to the level-1 queue.
+//   k_bounce   one queued ray per lane, same work; adds weight * lighting to its pixel and
+//              appends to the next level's queue.  Launched once per recursion level.
+// Queue appends are aggregated per wave: one atomic per 64-lane wave reserves a contiguous
+// run of slots, each lane writes its slot with 16-byte stores.
+#pragma once
+
+#include "rt_device.h"
+#include "rt_launch.h"
+
+namespace rtx {
+
+template <typename R> struct Vec2T;
+template <> struct Vec2T<double> { using type = double2; };
+template <> struct Vec2T<float> { using type = float2; };
+
+RT_DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+template <typename R> RT_DEV uint32_t pixel_bits_load(R v);
+template <> RT_DEV uint32_t pixel_bits_load<double>(double v) { return (uint32_t)__double_as_longlong(v); }
+template <> RT_DEV uint32_t pixel_bits_load<float>(float v) { return __float_as_uint(v); }
+template <typename R> RT_DEV R pixel_bits_store(uint32_t p);
+template <> RT_DEV double pixel_bits_store<double>(uint32_t p) { return __longlong_as_double((long long)p); }
+template <> RT_DEV float pixel_bits_store<float>(uint32_t p) { return __uint_as_float(p); }
+
+// Append (o, d, weight, pixel) for every lane with `active` set.  Must be reached by all
+// lanes of the wave that are still in the loop (inactive ones pass active = false).
+template <typename R>
+RT_DEV void queue_push(const QueueDev<R> &q, bool active, V3<R> o, V3<R> d, R weight, uint32_t pixel,
+                       uint32_t &overflow)
+{
+    const unsigned long long mask = __ballot(active);
+    if (mask == 0ull) return;
+    const uint32_t lane = lane_id();
+    const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(q.count, (uint32_t)__popcll(mask));
+    base = __shfl(base, (int)leader);
+    if (active) {
+        const uint32_t idx = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (idx < q.capacity) {
+            using V2 = typename Vec2T<R>::type;
+            V2 *dst = reinterpret_cast<V2 *>(q.rec) + (size_t)idx * 4;
+            V2 a, b, c, e;
+            a.x = o.x; a.y = o.y;
+            b.x = o.z; b.y = d.x;
+            c.x = d.y; c.y = d.z;
+            e.x = weight; e.y = pixel_bits_store<R>(pixel);
+            dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = e;
+        } else {
+            overflow = 1;
+        }
+    }
+}
+
+// Flush the per-lane counters: one atomic per wave and counter, spread over shards.
+RT_DEV void stats_flush(StatShard *stats, uint32_t level, uint32_t hits, uint32_t overflow)
+{
+    // wave totals via ballot-free butterfly on 32-bit values
+    for (int off = 32; off > 0; off >>= 1) {
+        hits += __shfl_xor(hits, off);
+        overflow |= __shfl_xor(overflow, off);
+    }
+    if (lane_id() == 0) {
+        StatShard *s = stats + (blockIdx.x % kStatShards);
+        if (hits) atomicAdd(&s->hits[level], (unsigned long long)hits);
+        if (overflow) atomicAdd(&s->overflow, 1ull);
+    }
+}
+
+template <typename R, uint32_t SF>
+__global__ void __launch_bounds__(kBlock)
+k_primary(CameraDev<R> cam, SceneDev<R> S, const double *__restrict__ rays, uint32_t pix_begin, uint32_t n_pix,
+          uint32_t remaining, R *__restrict__ fb, QueueDev<R> out_q, StatShard *__restrict__ stats)
+{
+    const uint32_t stride = gridDim.x * kBlock;
+    uint32_t hits = 0, overflow = 0;
+    for (uint32_t base = blockIdx.x * kBlock; base < n_pix; base += stride) {
+        const uint32_t k = base + threadIdx.x;
+        const bool valid = k < n_pix;
+        Node<R> nd;
+        nd.hit = false;
+        nd.has_reflect = nd.has_refract = false;
+        nd.lighting = { R(0), R(0), R(0) };
+        if (valid) {
+            V3<R> ro, rd;
+            if (rays) {
+                const double *r = rays + (size_t)k * 6;
+                ro = { R(r[0]), R(r[1]), R(r[2]) };
+                rd = { R(r[3]), R(r[4]), R(r[5]) };
+            } else {
+                const uint32_t p = pix_begin + k;
+                const uint32_t W = cam.hsize;
+                uint32_t y = (uint32_t)((double)p * cam.inv_hsize);
+                int32_t x = (int32_t)(p - y * W);
+                if (x < 0) { y -= 1; x += (int32_t)W; }
+                else if ((uint32_t)x >= W) { y += 1; x -= (int32_t)W; }
+                ray_for_pixel(cam, (uint32_t)x, y, ro, rd);
+            }
+            nd = trace_node<R, SF>(S, ro, rd, remaining);
+            R *px = fb + (size_t)k * 3;
+            px[0] = nd.lighting.x;
+            px[1] = nd.lighting.y;
+            px[2] = nd.lighting.z;
+            hits += nd.hit ? 1u : 0u;
+        }
+        if constexpr ((SF & SF_REFLECTIVE) != 0)
+            queue_push(out_q, valid && nd.has_reflect, nd.over_point, nd.reflectv, nd.reflect_factor, k, overflow);
+        if constexpr ((SF & SF_TRANSPARENT) != 0)
+            queue_push(out_q, valid && nd.has_refract, nd.under_point, nd.refract_dir, nd.refract_factor, k, overflow);
+    }
+    stats_flush(stats, 0, hits, overflow);
+}
+
+template <typename R> RT_DEV void fb_add(R *p, R v);
+template <> RT_DEV void fb_add<double>(double *p, double v) { unsafeAtomicAdd(p, v); }
+template <> RT_DEV void fb_add<float>(float *p, float v) { unsafeAtomicAdd(p, v); }
+
+template <typename R, uint32_t SF>
+__global__ void __launch_bounds__(kBlock)
+k_bounce(SceneDev<R> S, QueueDev<R> in_q, QueueDev<R> out_q, uint32_t remaining, uint32_t level,
+         R *__restrict__ fb, StatShard *__restrict__ stats)
+{
+    uint32_t n = *in_q.count;
+    if (n > in_q.capacity) n = in_q.capacity;
+    const uint32_t stride = gridDim.x * kBlock;
+    uint32_t hits = 0, overflow = 0;
+    for (uint32_t base = blockIdx.x * kBlock; base < n; base += stride) {
+        const uint32_t k = base + threadIdx.x;
+        const bool valid = k < n;
+        Node<R> nd;
+        nd.hit = false;
+        nd.has_reflect = nd.has_refract = false;
+        R weight = R(0);
+        uint32_t pixel = 0;
+        if (valid) {
+            using V2 = typename Vec2T<R>::type;
+            const V2 *src = reinterpret_cast<const V2 *>(in_q.rec) + (size_t)k * 4;
+            const V2 a = src[0], b = src[1], c = src[2], e = src[3];
+            V3<R> ro = { a.x, a.y, b.x };
+            V3<R> rd = { b.y, c.x, c.y };
+            weight = e.x;
+            pixel = pixel_bits_load<R>(e.y);
+            nd = trace_node<R, SF>(S, ro, rd, remaining);
+            if (nd.hit) {
+                R *px = fb + (size_t)pixel * 3;
+                fb_add<R>(px + 0, nd.lighting.x * weight);
+                fb_add<R>(px + 1, nd.lighting.y * weight);
+                fb_add<R>(px + 2, nd.lighting.z * weight);
+                hits += 1u;
+            }
+        }
+        if constexpr ((SF & SF_REFLECTIVE) != 0)
+            queue_push(out_q, valid && nd.has_reflect, nd.over_point, nd.reflectv, weight * nd.reflect_factor, pixel,
+                       overflow);
+        if constexpr ((SF & SF_TRANSPARENT) != 0)
+            queue_push(out_q, valid && nd.has_refract, nd.under_point, nd.refract_dir, weight * nd.refract_factor,
+                       pixel, overflow);
+    }
+    stats_flush(stats, level, hits, overflow);
+}
+
+template <typename R>
+__global__ void __launch_bounds__(kBlock)
+k_raygen(CameraDev<R> cam, uint32_t pix_begin, uint32_t n_pix, double *__restrict__ out)
+{
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < n_pix; k += stride) {
+        const uint32_t p = pix_begin + k;
+        const uint32_t W = cam.hsize;
+        uint32_t y = (uint32_t)((double)p * cam.inv_hsize);
+        int32_t x = (int32_t)(p - y * W);
+        if (x < 0) { y -= 1; x += (int32_t)W; }
+        else if ((uint32_t)x >= W) { y += 1; x -= (int32_t)W; }
+        V3<R> ro, rd;
+        ray_for_pixel(cam, (uint32_t)x, y, ro, rd);
+        double *o = out + (size_t)k * 6;
+        o[0] = ro.x; o[1] = ro.y; o[2] = ro.z;
+        o[3] = rd.x; o[4] = rd.y; o[5] = rd.z;
+    }
+}
+
+// src/scenes/canvas.rs:84-86: `(c * 255.999) as u8` -- truncation, saturating, NaN -> 0
+template <typename R>
+__global__ void __launch_bounds__(kBlock) k_quantize(const R *__restrict__ rgb, size_t n, uint8_t *__restrict__ out)
+{
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        R v = rgb[i] * R(255.999);
+        uint8_t q;
+        if (!(v == v) || v <= R(0)) q = 0;
+        else if (v >= R(255)) q = 255;
+        else q = (uint8_t)(int)v;
+        out[i] = q;
+    }
+}
+
+// ---- launchers --------------------------------------------------------------------------
+#define RTX_SF_SWITCH(sf, CALL)                                                            \
+    switch ((sf) & 7u) {                                                                   \
+    case 0u: CALL(0u); break;                                                              \
+    case 1u: CALL(1u); break;                                                              \
+    case 2u: CALL(2u); break;                                                              \
+    case 3u: CALL(3u); break;                                                              \
+    case 4u: CALL(4u); break;                                                              \
+    case 5u: CALL(5u); break;                                                              \
+    case 6u: CALL(6u); break;                                                              \
+    default: CALL(7u); break;                                                              \
+    }
+
+template <typename R>
+hipError_t Launch<R>::primary(uint32_t sf, uint32_t grid, hipStream_t stream, const CameraDev<R> &cam,
+                              const SceneDev<R> &scene, const double *rays, uint32_t pix_begin, uint32_t n_pix,
+                              uint32_t remaining, R *fb, const QueueDev<R> &out_q, StatShard *stats)
+{
+#define RTX_CALL(SFV)                                                                                          \
+    hipLaunchKernelGGL((k_primary<R, SFV | SF_PATTERN>), dim3(grid), dim3(kBlock), 0, stream, cam, scene, rays, \
+                       pix_begin, n_pix, remaining, fb, out_q, stats)
+    RTX_SF_SWITCH(sf, RTX_CALL)
+#undef RTX_CALL
+    return hipGetLastError();
+}
+
+template <typename R>
+hipError_t Launch<R>::bounce(uint32_t sf, uint32_t grid, hipStream_t stream, const SceneDev<R> &scene,
+                             const QueueDev<R> &in_q, const QueueDev<R> &out_q, uint32_t remaining, uint32_t level,
+                             R *fb, StatShard *stats)
+{
+    if ((sf & (SF_REFLECTIVE | SF_TRANSPARENT)) == 0) return hipSuccess;  // nothing can be queued
+#define RTX_CALL(SFV)                                                                                         \
+    if constexpr (((SFV) & (SF_REFLECTIVE | SF_TRANSPARENT)) != 0)                                            \
+        hipLaunchKernelGGL((k_bounce<R, SFV | SF_PATTERN>), dim3(grid), dim3(kBlock), 0, stream, scene, in_q, \
+                           out_q, remaining, level, fb, stats)
+    RTX_SF_SWITCH(sf, RTX_CALL)
+#undef RTX_CALL
+    return hipGetLastError();
+}
+
+template <typename R>
+hipError_t Launch<R>::raygen(uint32_t grid, hipStream_t stream, const CameraDev<R> &cam, uint32_t pix_begin,
+                             uint32_t n_pix, double *out)
+{
+    hipLaunchKernelGGL((k_raygen<R>), dim3(grid), dim3(kBlock), 0, stream, cam, pix_begin, n_pix, out);
+    return hipGetLastError();
+}
+
+template <typename R>
+hipError_t Launch<R>::quantize(uint32_t grid, hipStream_t stream, const R *rgb, size_t n, uint8_t *out)
+{
+    hipLaunchKernelGGL((k_quantize<R>), dim3(grid), dim3(kBlock), 0, stream, rgb, n, out);
+    return hipGetLastError();
+}
+
+}  // namespace rtx

@@ -1,0 +1,43 @@
+// rt_launch.h -- host-callable launchers of the render kernels, one set per scalar type.
+// The definitions live in render_f64.hip / render_f32.hip; the C ABI calls only these.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include "../../include/rtx.h"
+#include "rt_types.h"
+
+namespace rtx {
+
+// Threads per workgroup and the persistent grid every launch uses: the kernels walk their
+// work with a grid-stride loop, so the grid is sized to the chip, not to the frame.
+constexpr uint32_t kBlock = 256;
+
+template <typename R>
+struct Launch {
+    // Primary rays of pixels [pix_begin, pix_begin + n_pix) (or rays[0..n_pix) when rays is
+    // non-null): intersect, shade, store the lighting term at fb[3*k], queue the children.
+    static hipError_t primary(uint32_t sf, uint32_t grid, hipStream_t stream, const CameraDev<R> &cam,
+                              const SceneDev<R> &scene, const double *rays, uint32_t pix_begin, uint32_t n_pix,
+                              uint32_t remaining, R *fb, const QueueDev<R> &out_q, StatShard *stats);
+    // One recursion level below the primary rays: consume in_q, add weight * lighting into
+    // fb, queue the next level.
+    static hipError_t bounce(uint32_t sf, uint32_t grid, hipStream_t stream, const SceneDev<R> &scene,
+                             const QueueDev<R> &in_q, const QueueDev<R> &out_q, uint32_t remaining, uint32_t level,
+                             R *fb, StatShard *stats);
+    // Primary rays only (no tracing): out[6*k..] = origin, direction.
+    static hipError_t raygen(uint32_t grid, hipStream_t stream, const CameraDev<R> &cam, uint32_t pix_begin,
+                             uint32_t n_pix, double *out);
+    // (c * 255.999) as u8
+    static hipError_t quantize(uint32_t grid, hipStream_t stream, const R *rgb, size_t n, uint8_t *out);
+};
+
+// f64 only: intermediate results of one color_at node per ray.
+hipError_t launch_probe(uint32_t sf, uint32_t grid, hipStream_t stream, const SceneDev<double> &scene,
+                        const double *rays, uint32_t n, rtx_probe *out);
+
+extern template struct Launch<double>;
+extern template struct Launch<float>;
+
+}  // namespace rtx

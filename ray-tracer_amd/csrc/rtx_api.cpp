@@ -1,0 +1,760 @@
+// rtx_api.cpp -- the C ABI declared in include/rtx.h: contexts, scene upload (repacking the
+// caller's structure-of-arrays World into the device object table) and the render calls,
+// which drive the kernels of rt_kernels.h level by level.  Host code only; no arithmetic of
+// the render loop happens here apart from the camera origin, which the reference recomputes
+// per pixel (src/scenes/camera.rs:154) and which is the same value for every pixel.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/rtx.h"
+#include "rt_launch.h"
+
+using namespace rtx;
+
+namespace {
+
+thread_local std::string tl_error;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    tl_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(RTX_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+constexpr uint32_t kMaxLevels = 8;  // rtx_stats.rays_per_level entries; max_depth <= 7
+
+// Scratch of one in-flight render call.  A context keeps a pool of these so that calls from
+// different host threads overlap on the device instead of serialising.
+struct Slot {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
+    void *queues = nullptr;     // both ping-pong ray queues
+    size_t queue_bytes = 0;
+    void *fb = nullptr;         // device framebuffer for host-output calls
+    size_t fb_bytes = 0;
+    void *aux = nullptr;        // ray upload / probe output
+    size_t aux_bytes = 0;
+    uint32_t *counts = nullptr; // queue counters, kMaxLevels + 1 per chunk
+    size_t counts_n = 0;
+    StatShard *shards = nullptr;
+    hipEvent_t done = nullptr;  // recorded when a call returns with work still in flight
+    bool pending = false;
+    bool busy = false;
+};
+
+}  // namespace
+
+struct rtx_context {
+    int device = 0;
+    int cu_count = 256;
+    int clock_mhz = 0;
+    std::string name;
+    size_t workspace_limit = (size_t)8 << 30;
+    uint32_t blocks_per_cu = 8;
+    std::mutex mu;
+    std::vector<std::unique_ptr<Slot>> slots;
+};
+
+struct rtx_scene {
+    rtx_context *ctx = nullptr;
+    uint32_t n = 0;
+    uint32_t sf = 0;
+    void *d_hot64 = nullptr, *d_cold64 = nullptr, *d_hot32 = nullptr, *d_cold32 = nullptr;
+    SceneDev<double> dev64;
+    SceneDev<float> dev32;
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+int slot_acquire(rtx_context *ctx, Slot **out)
+{
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    for (auto &s : ctx->slots)
+        if (!s->busy) {
+            s->busy = true;
+            *out = s.get();
+            return RTX_OK;
+        }
+    std::unique_ptr<Slot> s(new Slot);
+    HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    for (auto &e : s->ev) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
+    HIP_TRY(hipMalloc((void **)&s->shards, sizeof(StatShard) * kStatShards));
+    s->busy = true;
+    *out = s.get();
+    ctx->slots.push_back(std::move(s));
+    return RTX_OK;
+}
+void slot_release(rtx_context *ctx, Slot *s)
+{
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    s->busy = false;
+}
+struct SlotLease {
+    rtx_context *ctx;
+    Slot *slot = nullptr;
+    explicit SlotLease(rtx_context *c) : ctx(c) {}
+    ~SlotLease()
+    {
+        if (slot) slot_release(ctx, slot);
+    }
+};
+
+int grow(void **ptr, size_t *have, size_t need)
+{
+    if (need <= *have) return RTX_OK;
+    if (*ptr) HIP_TRY(hipFree(*ptr));
+    *ptr = nullptr;
+    *have = 0;
+    HIP_TRY(hipMalloc(ptr, need));
+    *have = need;
+    return RTX_OK;
+}
+
+template <typename R>
+void fill_records(const rtx_scene_desc *d, const std::vector<uint8_t> &container, std::vector<HotRec<R>> &hot,
+                  std::vector<ColdRec<R>> &cold)
+{
+    const uint32_t n = d->n_objects;
+    hot.resize(n);
+    cold.resize(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        HotRec<R> &h = hot[i];
+        ColdRec<R> &c = cold[i];
+        std::memset(&h, 0, sizeof h);
+        std::memset(&c, 0, sizeof c);
+        const double *inv = d->inverse + (size_t)i * 16;
+        const double *invt = d->inverse_transposed + (size_t)i * 16;
+        const double *pinv = d->pattern_inverse + (size_t)i * 16;
+        for (int k = 0; k < 12; ++k) h.inv[k] = (R)inv[k];
+        h.ymin = (R)d->ymin[i];
+        h.ymax = (R)d->ymax[i];
+        h.type = d->shape_type[i];
+        h.flags = (d->closed[i] ? OF_CLOSED : 0u) | (d->casts_shadow[i] ? OF_CASTS_SHADOW : 0u) |
+                  (container[i] ? OF_CONTAINER : 0u);
+        for (int r = 0; r < 3; ++r)
+            for (int k = 0; k < 3; ++k) c.inv_t[r * 3 + k] = (R)invt[r * 4 + k];
+        for (int k = 0; k < 3; ++k) {
+            c.color[k] = (R)d->color[(size_t)i * 3 + k];
+            c.c1[k] = (R)d->pattern_color1[(size_t)i * 3 + k];
+            c.c2[k] = (R)d->pattern_color2[(size_t)i * 3 + k];
+        }
+        c.ambient = (R)d->ambient[i];
+        c.diffuse = (R)d->diffuse[i];
+        c.specular = (R)d->specular[i];
+        c.shininess = (R)d->shininess[i];
+        c.reflective = (R)d->reflective[i];
+        c.transparency = (R)d->transparency[i];
+        c.refractive_index = (R)d->refractive_index[i];
+        for (int k = 0; k < 12; ++k) c.pinv[k] = (R)pinv[k];
+        c.pattern_type = d->pattern_type[i];
+    }
+}
+
+template <typename R>
+CameraDev<R> make_camera(const rtx_camera_desc *cam)
+{
+    CameraDev<R> c;
+    std::memset(&c, 0, sizeof c);
+    const double *m = cam->inverse_transform;
+    for (int k = 0; k < 12; ++k) c.inv[k] = (R)m[k];
+    // inverse_transform * point(0, 0, 0), row by row as src/matrices/matrix4.rs:172-185 does it
+    for (int i = 0; i < 3; ++i) {
+        double val = 0.0;
+        const double other[4] = { 0.0, 0.0, 0.0, 1.0 };
+        for (int a = 0; a < 4; ++a) val += m[i * 4 + a] * other[a];
+        c.origin[i] = (R)val;
+    }
+    c.pixel_size = (R)cam->pixel_size;
+    c.half_width = (R)cam->half_width;
+    c.half_height = (R)cam->half_height;
+    c.hsize = cam->hsize;
+    c.vsize = cam->vsize;
+    c.inv_hsize = 1.0 / (double)cam->hsize;
+    return c;
+}
+
+template <typename R> const SceneDev<R> &scene_dev(const rtx_scene *s);
+template <> const SceneDev<double> &scene_dev<double>(const rtx_scene *s) { return s->dev64; }
+template <> const SceneDev<float> &scene_dev<float>(const rtx_scene *s) { return s->dev32; }
+
+uint32_t grid_for(const rtx_context *ctx, uint64_t n)
+{
+    uint64_t blocks = (n + kBlock - 1) / kBlock;
+    uint64_t cap = (uint64_t)ctx->cu_count * ctx->blocks_per_cu;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (uint32_t)blocks;
+}
+
+// Worst-case number of rays on recursion level L for one primary ray: every hit can spawn a
+// reflection ray (if any object reflects) and a refraction ray (if any object is transparent).
+uint64_t level_growth(uint32_t sf, uint32_t level)
+{
+    const uint64_t g = ((sf & SF_REFLECTIVE) ? 1u : 0u) + ((sf & SF_TRANSPARENT) ? 1u : 0u);
+    uint64_t v = 1;
+    for (uint32_t i = 0; i < level; ++i) v *= g;
+    return v;
+}
+
+struct FramePlan {
+    uint32_t levels = 0;         // bounce launches per chunk
+    uint64_t cap[2] = { 0, 0 };  // entries per primary ray in the odd / even level queue
+    uint64_t chunk_pix = 0;      // primary rays per chunk
+};
+
+// Split [0, n_pix) into chunks so that both ping-pong queues, sized for the worst case, fit
+// the workspace limit.  `align` keeps chunks on row boundaries for camera renders.
+template <typename R>
+int plan_frame(const rtx_context *ctx, uint32_t sf, uint32_t max_depth, uint64_t n_pix, uint64_t align, FramePlan *p)
+{
+    if (max_depth >= kMaxLevels) return fail(RTX_ERR_INVALID, "max_depth %u is not supported (limit %u)", max_depth, kMaxLevels - 1);
+    const bool secondary = (sf & (SF_REFLECTIVE | SF_TRANSPARENT)) != 0 && max_depth > 0;
+    p->levels = secondary ? max_depth : 0;
+    p->cap[0] = p->cap[1] = 0;
+    for (uint32_t L = 1; L <= p->levels; ++L) p->cap[L & 1] = std::max(p->cap[L & 1], level_growth(sf, L));
+    const uint64_t per_pix = (p->cap[0] + p->cap[1]) * 8 * sizeof(R);
+    uint64_t chunk = n_pix;
+    if (per_pix) {
+        chunk = std::min<uint64_t>(chunk, ctx->workspace_limit / per_pix);
+        // queue slots are indexed with 32 bits
+        chunk = std::min<uint64_t>(chunk, 0xfffffff0ull / std::max(p->cap[0], p->cap[1]));
+    }
+    chunk = std::min<uint64_t>(chunk, 0x7fffff00ull);
+    if (align > 1) chunk = (chunk / align) * align;
+    if (chunk == 0) return fail(RTX_ERR_INVALID, "workspace limit too small for one row of this frame");
+    p->chunk_pix = chunk;
+    return RTX_OK;
+}
+
+// Enqueue every kernel of one frame (or ray batch) on the slot's stream.
+template <typename R>
+int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Slot *slot, hipStream_t stream, const CameraDev<R> *cam,
+                  const double *d_rays, uint64_t first_pix, uint64_t n_pix, uint64_t align, uint32_t max_depth, R *d_fb,
+                  rtx_progress_fn progress, void *user, bool timed, uint32_t *n_chunks_out, uint32_t *n_launch_out)
+{
+    FramePlan plan;
+    int rc = plan_frame<R>(ctx, scene->sf, max_depth, n_pix, align, &plan);
+    if (rc) return rc;
+    const uint32_t n_chunks = (uint32_t)((n_pix + plan.chunk_pix - 1) / plan.chunk_pix);
+    const uint64_t cap0 = plan.cap[0] * plan.chunk_pix, cap1 = plan.cap[1] * plan.chunk_pix;
+    rc = grow(&slot->queues, &slot->queue_bytes, (size_t)((cap0 + cap1) * 8 * sizeof(R)));
+    if (rc) return rc;
+    const size_t counts_need = (size_t)n_chunks * (kMaxLevels + 1);
+    if (counts_need > slot->counts_n) {
+        if (slot->counts) HIP_TRY(hipFree(slot->counts));
+        slot->counts = nullptr;
+        slot->counts_n = 0;
+        HIP_TRY(hipMalloc((void **)&slot->counts, counts_need * sizeof(uint32_t)));
+        slot->counts_n = counts_need;
+    }
+    HIP_TRY(hipMemsetAsync(slot->counts, 0, counts_need * sizeof(uint32_t), stream));
+    HIP_TRY(hipMemsetAsync(slot->shards, 0, sizeof(StatShard) * kStatShards, stream));
+
+    R *q_odd = (R *)slot->queues;
+    R *q_even = q_odd + cap0 * 8;
+    CameraDev<R> cam_zero;
+    std::memset(&cam_zero, 0, sizeof cam_zero);
+    const SceneDev<R> &S = scene_dev<R>(scene);
+    uint32_t launches = 0;
+    if (timed) HIP_TRY(hipEventRecord(slot->ev[0], stream));
+    for (uint32_t c = 0; c < n_chunks; ++c) {
+        const uint64_t k0 = (uint64_t)c * plan.chunk_pix;
+        const uint32_t n = (uint32_t)std::min<uint64_t>(plan.chunk_pix, n_pix - k0);
+        uint32_t *counts = slot->counts + (size_t)c * (kMaxLevels + 1);
+        auto queue_at = [&](uint32_t level) {
+            QueueDev<R> q;
+            q.rec = (level & 1) ? q_odd : q_even;
+            q.count = counts + level;
+            q.capacity = (uint32_t)((level & 1) ? cap0 : cap1);
+            q.pad = 0;
+            if (level > plan.levels) q.capacity = 0;
+            return q;
+        };
+        R *fb = d_fb + k0 * 3;
+        if (timed && c == 0) HIP_TRY(hipEventRecord(slot->ev[2], stream));
+        HIP_TRY(Launch<R>::primary(scene->sf, grid_for(ctx, n), stream, cam ? *cam : cam_zero, S,
+                                   d_rays ? d_rays + k0 * 6 : nullptr, (uint32_t)(first_pix + k0), n, max_depth, fb,
+                                   queue_at(1), slot->shards));
+        if (timed && c == 0) HIP_TRY(hipEventRecord(slot->ev[3], stream));
+        ++launches;
+        for (uint32_t L = 1; L <= plan.levels; ++L) {
+            const uint64_t worst = std::min<uint64_t>((uint64_t)n * level_growth(scene->sf, L), 0xffffffffull);
+            HIP_TRY(Launch<R>::bounce(scene->sf, grid_for(ctx, worst), stream, S, queue_at(L), queue_at(L + 1),
+                                      max_depth - L, L, fb, slot->shards));
+            ++launches;
+        }
+        if (progress) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            progress(k0 + n, user);
+        }
+    }
+    if (timed) HIP_TRY(hipEventRecord(slot->ev[1], stream));
+    if (n_chunks_out) *n_chunks_out = n_chunks;
+    if (n_launch_out) *n_launch_out = launches;
+    return RTX_OK;
+}
+
+// After the stream has drained: gather counters into stats; report a queue overflow.
+int collect_stats(Slot *slot, uint32_t n_chunks, uint64_t n_primary, bool timed, rtx_stats *stats)
+{
+    std::vector<StatShard> shards(kStatShards);
+    HIP_TRY(hipMemcpy(shards.data(), slot->shards, sizeof(StatShard) * kStatShards, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> counts((size_t)n_chunks * (kMaxLevels + 1));
+    HIP_TRY(hipMemcpy(counts.data(), slot->counts, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    uint64_t overflow = 0;
+    for (auto &s : shards) overflow += s.overflow;
+    if (overflow) return fail(RTX_ERR_DEVICE, "secondary-ray queue overflow (internal sizing error)");
+    if (!stats) return RTX_OK;
+    std::memset(stats->rays_per_level, 0, sizeof stats->rays_per_level);
+    stats->rays_per_level[0] = n_primary;
+    for (uint32_t c = 0; c < n_chunks; ++c)
+        for (uint32_t L = 1; L < kMaxLevels; ++L) stats->rays_per_level[L] += counts[(size_t)c * (kMaxLevels + 1) + L];
+    stats->color_rays = 0;
+    for (uint32_t L = 0; L < kMaxLevels; ++L) stats->color_rays += stats->rays_per_level[L];
+    stats->shadow_rays = 0;
+    for (auto &s : shards)
+        for (uint32_t L = 0; L < kMaxLevels; ++L) stats->shadow_rays += s.hits[L];
+    if (timed) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, slot->ev[0], slot->ev[1]));
+        stats->kernel_ms = ms;
+        HIP_TRY(hipEventElapsedTime(&ms, slot->ev[2], slot->ev[3]));
+        stats->primary_kernel_ms = ms;
+    }
+    return RTX_OK;
+}
+
+int check_camera(const rtx_camera_desc *cam, uint32_t row_begin, uint32_t row_end)
+{
+    if (!cam) return fail(RTX_ERR_INVALID, "camera is NULL");
+    if (cam->hsize == 0 || cam->vsize == 0) return fail(RTX_ERR_INVALID, "camera has an empty canvas");
+    if (row_begin > row_end || row_end > cam->vsize)
+        return fail(RTX_ERR_INVALID, "rows [%u, %u) are outside the %u-row canvas", row_begin, row_end, cam->vsize);
+    if ((uint64_t)cam->hsize * cam->vsize > 0x7fffffffull) return fail(RTX_ERR_INVALID, "canvas has more than 2^31 pixels");
+    for (int k = 0; k < 16; ++k)
+        if (!std::isfinite(cam->inverse_transform[k])) return fail(RTX_ERR_INVALID, "camera inverse_transform is not finite");
+    return RTX_OK;
+}
+
+template <typename R>
+int render_impl(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_desc *cam, uint32_t max_depth,
+                uint32_t row_begin, uint32_t row_end, void *host_out, void *dev_out, hipStream_t user_stream,
+                rtx_progress_fn progress, void *user, rtx_stats *stats)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return fail(RTX_ERR_DEVICE, "hipSetDevice(%d) failed", ctx->device);
+    SlotLease lease(ctx);
+    int rc = slot_acquire(ctx, &lease.slot);
+    if (rc) return rc;
+    Slot *slot = lease.slot;
+    const uint64_t W = cam->hsize;
+    const uint64_t n_pix = (uint64_t)(row_end - row_begin) * W;
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (n_pix == 0) return RTX_OK;
+    hipStream_t stream = user_stream ? user_stream : slot->stream;
+    // an earlier asynchronous call may still be using this slot's scratch on another stream
+    if (slot->pending) {
+        HIP_TRY(hipStreamWaitEvent(stream, slot->done, 0));
+        slot->pending = false;
+    }
+    R *d_fb = (R *)dev_out;
+    if (!d_fb) {
+        rc = grow(&slot->fb, &slot->fb_bytes, (size_t)(n_pix * 3 * sizeof(R)));
+        if (rc) return rc;
+        d_fb = (R *)slot->fb;
+    }
+    const CameraDev<R> cd = make_camera<R>(cam);
+    uint32_t n_chunks = 0, n_launch = 0;
+    const bool sync = host_out != nullptr || stats != nullptr;
+    rc = enqueue_frame<R>(ctx, scene, slot, stream, &cd, nullptr, (uint64_t)row_begin * W, n_pix, W, max_depth, d_fb,
+                          progress, user, sync, &n_chunks, &n_launch);
+    if (rc) return rc;
+    if (!sync) {
+        HIP_TRY(hipEventRecord(slot->done, stream));
+        slot->pending = true;
+        return RTX_OK;
+    }
+    if (host_out) HIP_TRY(hipMemcpyAsync(host_out, d_fb, (size_t)(n_pix * 3 * sizeof(R)), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    rc = collect_stats(slot, n_chunks, n_pix, true, stats);
+    if (rc) return rc;
+    if (stats) {
+        stats->n_chunks = n_chunks;
+        stats->n_launches = n_launch;
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return RTX_OK;
+}
+
+template <typename R>
+int trace_impl(rtx_context *ctx, const rtx_scene *scene, const double *rays, size_t n, uint32_t max_depth,
+               double *out_rgb, rtx_stats *stats)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return fail(RTX_ERR_DEVICE, "hipSetDevice(%d) failed", ctx->device);
+    SlotLease lease(ctx);
+    int rc = slot_acquire(ctx, &lease.slot);
+    if (rc) return rc;
+    Slot *slot = lease.slot;
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (n == 0) return RTX_OK;
+    const size_t ray_bytes = n * 6 * sizeof(double);
+    rc = grow(&slot->aux, &slot->aux_bytes, ray_bytes);
+    if (rc) return rc;
+    rc = grow(&slot->fb, &slot->fb_bytes, n * 3 * sizeof(R));
+    if (rc) return rc;
+    hipStream_t stream = slot->stream;
+    HIP_TRY(hipMemcpyAsync(slot->aux, rays, ray_bytes, hipMemcpyHostToDevice, stream));
+    uint32_t n_chunks = 0, n_launch = 0;
+    rc = enqueue_frame<R>(ctx, scene, slot, stream, nullptr, (const double *)slot->aux, 0, n, 1, max_depth, (R *)slot->fb,
+                          nullptr, nullptr, true, &n_chunks, &n_launch);
+    if (rc) return rc;
+    std::vector<R> tmp;
+    void *dst = out_rgb;
+    if (sizeof(R) != sizeof(double)) {
+        tmp.resize(n * 3);
+        dst = tmp.data();
+    }
+    HIP_TRY(hipMemcpyAsync(dst, slot->fb, n * 3 * sizeof(R), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (sizeof(R) != sizeof(double))
+        for (size_t i = 0; i < n * 3; ++i) out_rgb[i] = (double)tmp[i];
+    rc = collect_stats(slot, n_chunks, n, true, stats);
+    if (rc) return rc;
+    if (stats) {
+        stats->n_chunks = n_chunks;
+        stats->n_launches = n_launch;
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return RTX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rtx_last_error(void) { return tl_error.c_str(); }
+
+int rtx_context_create(int device_id, rtx_context **out)
+{
+    if (!out) return fail(RTX_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(RTX_ERR_DEVICE, "no HIP device is visible: the render loop has no CPU fallback");
+    if (device_id < 0) HIP_TRY(hipGetDevice(&device_id));
+    if (device_id >= count) return fail(RTX_ERR_INVALID, "device %d does not exist (%d visible)", device_id, count);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(RTX_ERR_DEVICE, "device %d is %s; the kernels are built for gfx950 only", device_id, prop.gcnArchName);
+    std::unique_ptr<rtx_context> ctx(new rtx_context);
+    ctx->device = device_id;
+    ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    ctx->clock_mhz = prop.clockRate / 1000;
+    ctx->name = prop.name;
+    if (const char *e = std::getenv("RTX_BLOCKS_PER_CU")) {
+        int v = std::atoi(e);
+        if (v >= 1 && v <= 64) ctx->blocks_per_cu = (uint32_t)v;
+    }
+    *out = ctx.release();
+    return RTX_OK;
+}
+
+void rtx_context_destroy(rtx_context *ctx)
+{
+    if (!ctx) return;
+    {
+        DeviceGuard guard(ctx->device);
+        for (auto &s : ctx->slots) {
+            if (s->stream) (void)hipStreamSynchronize(s->stream);
+            if (s->queues) (void)hipFree(s->queues);
+            if (s->fb) (void)hipFree(s->fb);
+            if (s->aux) (void)hipFree(s->aux);
+            if (s->counts) (void)hipFree(s->counts);
+            if (s->shards) (void)hipFree(s->shards);
+            if (s->done) (void)hipEventDestroy(s->done);
+            for (auto &e : s->ev)
+                if (e) (void)hipEventDestroy(e);
+            if (s->stream) (void)hipStreamDestroy(s->stream);
+        }
+    }
+    delete ctx;
+}
+
+int rtx_context_set_workspace_limit(rtx_context *ctx, size_t bytes)
+{
+    if (!ctx) return fail(RTX_ERR_INVALID, "ctx is NULL");
+    if (bytes < ((size_t)1 << 20)) return fail(RTX_ERR_INVALID, "workspace limit below 1 MiB");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->workspace_limit = bytes;
+    return RTX_OK;
+}
+
+int rtx_scene_upload(rtx_context *ctx, const rtx_scene_desc *d, rtx_scene **out)
+{
+    if (!ctx || !d || !out) return fail(RTX_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    const uint32_t n = d->n_objects;
+    if (n > 0) {
+        if (!d->shape_type || !d->inverse || !d->inverse_transposed || !d->ymin || !d->ymax || !d->closed || !d->color ||
+            !d->ambient || !d->diffuse || !d->specular || !d->shininess || !d->reflective || !d->transparency ||
+            !d->refractive_index || !d->casts_shadow || !d->pattern_type || !d->pattern_inverse || !d->pattern_color1 ||
+            !d->pattern_color2)
+            return fail(RTX_ERR_INVALID, "scene description has a NULL array");
+        // World::shade_hit and is_shadowed index lights[0] (src/scenes/world.rs:123,147): the
+        // reference panics on the first hit of a world without lights.
+        if (d->n_lights == 0 || !d->light_position || !d->light_intensity)
+            return fail(RTX_ERR_INVALID, "world has objects but no light: the reference panics at lights[0]");
+    }
+    for (uint32_t i = 0; i < n; ++i) {
+        if (d->shape_type[i] > RTX_CONE) return fail(RTX_ERR_INVALID, "object %u: unknown shape tag %u", i, d->shape_type[i]);
+        if (d->pattern_type[i] > RTX_TEST) return fail(RTX_ERR_INVALID, "object %u: unknown pattern tag %u", i, d->pattern_type[i]);
+        for (int k = 0; k < 16; ++k)
+            if (!std::isfinite(d->inverse[(size_t)i * 16 + k]) || !std::isfinite(d->inverse_transposed[(size_t)i * 16 + k]))
+                return fail(RTX_ERR_INVALID, "object %u: transform is not finite", i);
+    }
+    // Refraction containers (src/scenes/world.rs:253-285) find and remove objects by value
+    // equality, so k objects that compare equal toggle one list entry k times per shared t:
+    // an even class never appears in the list, an odd one appears once.  Its lowest index is
+    // the only member that can be the hit (ties go to the lowest index), so it carries the flag.
+    std::vector<uint8_t> container(n, 1);
+    if (d->eq_class) {
+        std::map<uint32_t, std::pair<uint32_t, uint32_t>> classes;  // class -> (first index, members)
+        for (uint32_t i = 0; i < n; ++i) {
+            auto it = classes.find(d->eq_class[i]);
+            if (it == classes.end()) classes.emplace(d->eq_class[i], std::make_pair(i, 1u));
+            else it->second.second++;
+        }
+        for (uint32_t i = 0; i < n; ++i) {
+            const auto &c = classes[d->eq_class[i]];
+            container[i] = (c.first == i && (c.second & 1u)) ? 1 : 0;
+        }
+    }
+    uint32_t sf = n ? SF_ALL_CAST : 0u;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (d->reflective[i] != 0.0) sf |= SF_REFLECTIVE;
+        if (d->transparency[i] != 0.0) sf |= SF_TRANSPARENT;
+        if (!d->casts_shadow[i]) sf &= ~SF_ALL_CAST;
+        if (d->pattern_type[i] != RTX_SOLID) sf |= SF_PATTERN;
+    }
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return fail(RTX_ERR_DEVICE, "hipSetDevice(%d) failed", ctx->device);
+    std::unique_ptr<rtx_scene> s(new rtx_scene);
+    s->ctx = ctx;
+    s->n = n;
+    s->sf = sf;
+    std::vector<HotRec<double>> hot64;
+    std::vector<ColdRec<double>> cold64;
+    std::vector<HotRec<float>> hot32;
+    std::vector<ColdRec<float>> cold32;
+    fill_records<double>(d, container, hot64, cold64);
+    fill_records<float>(d, container, hot32, cold32);
+    auto upload = [&](void **dst, const void *src, size_t bytes) -> int {
+        HIP_TRY(hipMalloc(dst, std::max<size_t>(bytes, 256)));
+        if (bytes) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+        return RTX_OK;
+    };
+    int rc = upload(&s->d_hot64, hot64.data(), hot64.size() * sizeof(HotRec<double>));
+    if (!rc) rc = upload(&s->d_cold64, cold64.data(), cold64.size() * sizeof(ColdRec<double>));
+    if (!rc) rc = upload(&s->d_hot32, hot32.data(), hot32.size() * sizeof(HotRec<float>));
+    if (!rc) rc = upload(&s->d_cold32, cold32.data(), cold32.size() * sizeof(ColdRec<float>));
+    if (rc) {
+        rtx_scene_destroy(s.release());
+        return rc;
+    }
+    std::memset(&s->dev64, 0, sizeof s->dev64);
+    std::memset(&s->dev32, 0, sizeof s->dev32);
+    s->dev64.hot = (const HotRec<double> *)s->d_hot64;
+    s->dev64.cold = (const ColdRec<double> *)s->d_cold64;
+    s->dev32.hot = (const HotRec<float> *)s->d_hot32;
+    s->dev32.cold = (const ColdRec<float> *)s->d_cold32;
+    s->dev64.n = s->dev32.n = n;
+    s->dev64.flags = s->dev32.flags = sf;
+    if (d->n_lights > 0 && d->light_position && d->light_intensity)
+        for (int k = 0; k < 3; ++k) {
+            s->dev64.light_pos[k] = d->light_position[k];
+            s->dev64.light_int[k] = d->light_intensity[k];
+            s->dev32.light_pos[k] = (float)d->light_position[k];
+            s->dev32.light_int[k] = (float)d->light_intensity[k];
+        }
+    *out = s.release();
+    return RTX_OK;
+}
+
+void rtx_scene_destroy(rtx_scene *s)
+{
+    if (!s) return;
+    {
+        DeviceGuard guard(s->ctx->device);
+        if (s->d_hot64) (void)hipFree(s->d_hot64);
+        if (s->d_cold64) (void)hipFree(s->d_cold64);
+        if (s->d_hot32) (void)hipFree(s->d_hot32);
+        if (s->d_cold32) (void)hipFree(s->d_cold32);
+    }
+    delete s;
+}
+
+int rtx_render(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_desc *camera, uint32_t max_depth, int precision,
+               uint32_t row_begin, uint32_t row_end, void *out_rgb, size_t out_bytes, rtx_progress_fn progress, void *user,
+               rtx_stats *stats)
+{
+    if (!ctx || !scene || scene->ctx != ctx) return fail(RTX_ERR_INVALID, "scene does not belong to this context");
+    int rc = check_camera(camera, row_begin, row_end);
+    if (rc) return rc;
+    if (precision != RTX_F64 && precision != RTX_F32) return fail(RTX_ERR_INVALID, "unknown precision %d", precision);
+    const size_t elem = precision == RTX_F64 ? sizeof(double) : sizeof(float);
+    const size_t need = (size_t)(row_end - row_begin) * camera->hsize * 3 * elem;
+    if (need && (!out_rgb || out_bytes < need)) return fail(RTX_ERR_INVALID, "output buffer holds %zu bytes, %zu needed", out_bytes, need);
+    if (precision == RTX_F64)
+        return render_impl<double>(ctx, scene, camera, max_depth, row_begin, row_end, out_rgb, nullptr, nullptr, progress, user, stats);
+    return render_impl<float>(ctx, scene, camera, max_depth, row_begin, row_end, out_rgb, nullptr, nullptr, progress, user, stats);
+}
+
+int rtx_render_device(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_desc *camera, uint32_t max_depth,
+                      int precision, uint32_t row_begin, uint32_t row_end, void *d_out_rgb, size_t out_bytes, void *stream,
+                      rtx_stats *stats)
+{
+    if (!ctx || !scene || scene->ctx != ctx) return fail(RTX_ERR_INVALID, "scene does not belong to this context");
+    int rc = check_camera(camera, row_begin, row_end);
+    if (rc) return rc;
+    if (precision != RTX_F64 && precision != RTX_F32) return fail(RTX_ERR_INVALID, "unknown precision %d", precision);
+    const size_t elem = precision == RTX_F64 ? sizeof(double) : sizeof(float);
+    const size_t need = (size_t)(row_end - row_begin) * camera->hsize * 3 * elem;
+    if (need && (!d_out_rgb || out_bytes < need)) return fail(RTX_ERR_INVALID, "output buffer holds %zu bytes, %zu needed", out_bytes, need);
+    if (precision == RTX_F64)
+        return render_impl<double>(ctx, scene, camera, max_depth, row_begin, row_end, nullptr, d_out_rgb, (hipStream_t)stream, nullptr, nullptr, stats);
+    return render_impl<float>(ctx, scene, camera, max_depth, row_begin, row_end, nullptr, d_out_rgb, (hipStream_t)stream, nullptr, nullptr, stats);
+}
+
+int rtx_trace_rays(rtx_context *ctx, const rtx_scene *scene, const double *rays, size_t n, uint32_t max_depth, int precision,
+                   double *out_rgb, rtx_stats *stats)
+{
+    if (!ctx || !scene || scene->ctx != ctx) return fail(RTX_ERR_INVALID, "scene does not belong to this context");
+    if (n && (!rays || !out_rgb)) return fail(RTX_ERR_INVALID, "NULL ray or output array");
+    if (n > 0x7fffff00ull) return fail(RTX_ERR_INVALID, "too many rays in one batch");
+    if (precision == RTX_F64) return trace_impl<double>(ctx, scene, rays, n, max_depth, out_rgb, stats);
+    if (precision == RTX_F32) return trace_impl<float>(ctx, scene, rays, n, max_depth, out_rgb, stats);
+    return fail(RTX_ERR_INVALID, "unknown precision %d", precision);
+}
+
+int rtx_probe_rays(rtx_context *ctx, const rtx_scene *scene, const double *rays, size_t n, rtx_probe *out)
+{
+    if (!ctx || !scene || scene->ctx != ctx) return fail(RTX_ERR_INVALID, "scene does not belong to this context");
+    if (n == 0) return RTX_OK;
+    if (!rays || !out) return fail(RTX_ERR_INVALID, "NULL ray or output array");
+    if (n > 0x7fffff00ull) return fail(RTX_ERR_INVALID, "too many rays in one batch");
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return fail(RTX_ERR_DEVICE, "hipSetDevice(%d) failed", ctx->device);
+    SlotLease lease(ctx);
+    int rc = slot_acquire(ctx, &lease.slot);
+    if (rc) return rc;
+    Slot *slot = lease.slot;
+    const size_t ray_bytes = n * 6 * sizeof(double);
+    const size_t ray_pad = (ray_bytes + 255) & ~(size_t)255;
+    rc = grow(&slot->aux, &slot->aux_bytes, ray_pad + n * sizeof(rtx_probe));
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(slot->aux, rays, ray_bytes, hipMemcpyHostToDevice, slot->stream));
+    rtx_probe *d_out = (rtx_probe *)((char *)slot->aux + ray_pad);
+    HIP_TRY(launch_probe(scene->sf, grid_for(ctx, n), slot->stream, scene->dev64, (const double *)slot->aux, (uint32_t)n, d_out));
+    HIP_TRY(hipMemcpyAsync(out, d_out, n * sizeof(rtx_probe), hipMemcpyDeviceToHost, slot->stream));
+    HIP_TRY(hipStreamSynchronize(slot->stream));
+    return RTX_OK;
+}
+
+int rtx_generate_rays(rtx_context *ctx, const rtx_camera_desc *camera, uint64_t first_pixel, size_t n, double *out)
+{
+    if (!ctx) return fail(RTX_ERR_INVALID, "ctx is NULL");
+    int rc = check_camera(camera, 0, camera ? camera->vsize : 0);
+    if (rc) return rc;
+    if (n == 0) return RTX_OK;
+    if (!out) return fail(RTX_ERR_INVALID, "out is NULL");
+    if (first_pixel + n > (uint64_t)camera->hsize * camera->vsize) return fail(RTX_ERR_INVALID, "pixel range is outside the canvas");
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return fail(RTX_ERR_DEVICE, "hipSetDevice(%d) failed", ctx->device);
+    SlotLease lease(ctx);
+    rc = slot_acquire(ctx, &lease.slot);
+    if (rc) return rc;
+    Slot *slot = lease.slot;
+    rc = grow(&slot->aux, &slot->aux_bytes, n * 6 * sizeof(double));
+    if (rc) return rc;
+    const CameraDev<double> cd = make_camera<double>(camera);
+    HIP_TRY(Launch<double>::raygen(grid_for(ctx, n), slot->stream, cd, (uint32_t)first_pixel, (uint32_t)n, (double *)slot->aux));
+    HIP_TRY(hipMemcpyAsync(out, slot->aux, n * 6 * sizeof(double), hipMemcpyDeviceToHost, slot->stream));
+    HIP_TRY(hipStreamSynchronize(slot->stream));
+    return RTX_OK;
+}
+
+int rtx_quantize_u8_device(rtx_context *ctx, const void *d_rgb, int precision, size_t n_values, uint8_t *d_out, void *stream)
+{
+    if (!ctx) return fail(RTX_ERR_INVALID, "ctx is NULL");
+    if (n_values == 0) return RTX_OK;
+    if (!d_rgb || !d_out) return fail(RTX_ERR_INVALID, "NULL device pointer");
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return fail(RTX_ERR_DEVICE, "hipSetDevice(%d) failed", ctx->device);
+    hipStream_t s = (hipStream_t)stream;
+    SlotLease lease(ctx);
+    if (!s) {
+        int rc = slot_acquire(ctx, &lease.slot);
+        if (rc) return rc;
+        s = lease.slot->stream;
+    }
+    const uint32_t grid = grid_for(ctx, n_values);
+    if (precision == RTX_F64) HIP_TRY(Launch<double>::quantize(grid, s, (const double *)d_rgb, n_values, d_out));
+    else if (precision == RTX_F32) HIP_TRY(Launch<float>::quantize(grid, s, (const float *)d_rgb, n_values, d_out));
+    else return fail(RTX_ERR_INVALID, "unknown precision %d", precision);
+    if (!stream) HIP_TRY(hipStreamSynchronize(s));
+    return RTX_OK;
+}
+
+int rtx_device_info(rtx_context *ctx, char *name, size_t name_bytes, int *compute_units, int *clock_mhz)
+{
+    if (!ctx) return fail(RTX_ERR_INVALID, "ctx is NULL");
+    if (name && name_bytes) snprintf(name, name_bytes, "%s", ctx->name.c_str());
+    if (compute_units) *compute_units = ctx->cu_count;
+    if (clock_mhz) *clock_mhz = ctx->clock_mhz;
+    return RTX_OK;
+}
+
+}  // extern "C"
