@@ -1,0 +1,377 @@
+"""GPU parity: the HIP render path (through the C ABI) against the CPU oracle on the same
+seeded inputs.  Geometry (hit distance, hit object, points, normals, refractive indices,
+shadow decisions) must be bit-identical; colours may differ by the device's pow() rounding
+and the order in which a pixel's recursion levels are summed, bounded here by 1e-9 (f64 path).
+"""
+import math
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-9  # per channel, f64 path
+
+
+def random_rays(rng, n, box=6.0, toward=None):
+    o = rng.uniform(-box, box, size=(n, 3))
+    if toward is None:
+        d = rng.normal(size=(n, 3))
+    else:
+        d = (np.asarray(toward) + rng.normal(scale=1.5, size=(n, 3))) - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return np.concatenate([o, d], axis=1)
+
+
+def oracle_probe(orc, world, rays):
+    """What the oracle's intersect_world / hit_world / prepare_computations give per ray."""
+    out = []
+    objs = [world.object(i) for i in range(len(world))]
+    for r in rays:
+        ts, idx = orc.world_intersect(world, r)
+        hit = next((k for k, t in enumerate(ts) if t >= 0.0), None)
+        if hit is None:
+            out.append(None)
+            continue
+        c = orc.prepare_computations(ts, [objs[i] for i in idx], hit, r)
+        out.append((ts[hit], idx[hit], c))
+    return out
+
+
+def assert_probe_matches(orc, rta, scene_fn, rays, **kw):
+    ow, _ = scene_fn(orc.api, **kw)
+    gw, _ = scene_fn(rta.api, **kw)
+    got = rta.probe(gw, rays)
+    want = oracle_probe(orc, ow, rays)
+    n_hit = 0
+    for g, w, r in zip(got, want, rays):
+        if w is None:
+            assert g["object"] == -1, "GPU hit where the oracle missed: ray %s" % (r,)
+            continue
+        n_hit += 1
+        t, obj, c = w
+        assert g["object"] == obj and g["t"] == t, "hit differs for ray %s: GPU (%d, %r) oracle (%d, %r)" % (
+            r, g["object"], g["t"], obj, t)
+        assert np.array_equal(g["point"], c.point[:])
+        assert np.array_equal(g["normalv"], c.normalv[:])
+        assert np.array_equal(g["over_point"], c.over_point[:])
+        assert np.array_equal(g["under_point"], c.under_point[:])
+        assert np.array_equal(g["reflectv"], c.reflectv[:])
+        assert g["inside"] == c.inside
+        assert g["shadowed"] == int(orc.is_shadowed(ow, c.over_point[:]))
+    return n_hit
+
+
+def shapes_scene(api, kind=0):
+    """One transformed instance of every shape; `kind` toggles cast-shadow and transparency so
+    that every kernel specialisation gets exercised."""
+    from ray_tracer_amd.scene_api import CHECKER3D, GRADIENT, RING, STRIPE, TEST
+    w = api.world()
+    w.add_object(api.sphere().translate(-2.0, 0.5, 0.0).scale(1.2, 0.8, 1.0).rotate_z(0.4))
+    w.add_object(api.plane().translate_y(-1.5).rotate_x(0.1).set_pattern(CHECKER3D, (1, 1, 1), (0.1, 0.1, 0.1)))
+    w.add_object(api.cube().translate(2.0, 0.3, 1.0).rotate_y(0.7).scale(0.8, 1.1, 0.6).set_pattern(STRIPE, (1, 0, 0), (0, 0, 1))
+                 .set_pattern_transform(api.m_scaling(0.25, 0.25, 0.25)))
+    w.add_object(api.cylinder(-0.5, 1.0, True).translate(0.0, 0.0, 2.5).rotate_x(0.5).set_pattern(RING, (0, 1, 0), (1, 1, 0))
+                 .set_pattern_transform(api.m_scaling(0.2, 0.2, 0.2)))
+    w.add_object(api.cone(-1.0, 0.5, True).translate(0.5, 1.0, -2.0).rotate_z(-0.3).shear_xy(0.2)
+                 .set_pattern(GRADIENT, (1, 0, 1), (0, 1, 1)))
+    w.add_object(api.cylinder(-1.0, 1.0, False).translate(-3.0, 0.0, 3.0).scale(0.5, 1.0, 0.5))
+    w.add_object(api.cone().translate(4.0, 0.0, 4.0).scale(0.3, 0.3, 0.3).set_pattern(TEST))
+    if kind >= 1:
+        w.object(0).set_reflective(0.4)
+        w.object(2).set_reflective(0.2)
+    if kind >= 2:
+        w.object(0).set_transparency(0.7).set_refractive_index(1.4)
+        w.object(3).set_transparency(0.5).set_refractive_index(1.2).set_reflective(0.3)
+    if kind == 3:
+        w.object(0).set_casts_shadow(False)
+    w.add_light((-6.0, 9.0, -7.0), (1.0, 0.9, 0.8))
+    cam = api.camera(97, 61, math.pi / 3)
+    cam.set_view((0.5, 2.5, -8.0), (0.0, 0.3, 0.0), (0.1, 1.0, 0.0))
+    return w, cam
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+def test_probe_every_shape(orc, rta, kind):
+    rng = np.random.default_rng(100 + kind)
+    rays = np.concatenate([random_rays(rng, 1500, toward=(0, 0, 1)), random_rays(rng, 500)])
+    n_hit = assert_probe_matches(orc, rta, shapes_scene, rays, kind=kind)
+    assert n_hit > 800
+
+
+def axis_rays():
+    """Rays along the axes and through edges/corners: tangent hits, |d| < EPSILON branches,
+    cap rims, rays starting on and inside surfaces."""
+    rays = []
+    for o in [(0, 0, -5), (0, 1, -5), (1, 1, -5), (0, 0, 0), (0.5, 0.5, 0.5), (1, 0, 0), (0, 0.99999, -5), (0, 1.00001, -5)]:
+        for d in [(0, 0, 1), (0, 1, 0), (1, 0, 0), (0, -1, 0), (0, 0, -1), (1e-6, 0, 1), (0, 1e-6, 1), (1, 1, 1), (0, 1, 1)]:
+            dv = np.array(d, dtype=float)
+            rays.append(list(o) + list(dv / np.linalg.norm(dv)))
+    return np.array(rays)
+
+
+def unit_shapes_scene(api, shape=0):
+    w = api.world()
+    o = [api.sphere, api.plane, api.cube, lambda: api.cylinder(-1.0, 1.0, True), lambda: api.cone(-1.0, 1.0, True),
+         api.cylinder, api.cone][shape]()
+    w.add_object(o)
+    w.add_light((-10, 10, -10))
+    return w, api.camera(8, 8, 1.0)
+
+
+@pytest.mark.parametrize("shape", range(7))
+def test_probe_degenerate_rays(orc, rta, shape):
+    assert_probe_matches(orc, rta, unit_shapes_scene, axis_rays(), shape=shape)
+
+
+def nested_glass_scene(api, seed=0):
+    """Concentric and overlapping transparent spheres and cubes: the refraction container list
+    (prepare_computations, src/scenes/world.rs:253-285) has several entries at most hits."""
+    rng = np.random.default_rng(seed)
+    w = api.world()
+    for i in range(7):
+        o = api.sphere() if i % 3 else api.cube()
+        s = rng.uniform(0.6, 2.5)
+        o.translate(*rng.uniform(-0.8, 0.8, size=3)).scale(s, s, s)
+        o.set_transparency(rng.uniform(0.3, 1.0)).set_refractive_index(1.0 + 0.25 * (i + 1)).set_reflective(0.1 * (i % 4))
+        w.add_object(o)
+    w.add_object(api.sphere().scale(0.5, 0.5, 0.5))  # opaque core
+    if seed % 2:
+        w.add_object(api.sphere().scale(0.5, 0.5, 0.5))  # value-identical twin: aliases in the container list
+    w.add_light((-10, 10, -10))
+    return w, api.camera(64, 48, 1.0)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_refractive_indices_match(orc, rta, seed):
+    rng = np.random.default_rng(seed)
+    rays = random_rays(rng, 1200, box=3.0, toward=(0, 0, 0))
+    ow, _ = nested_glass_scene(orc.api, seed)
+    gw, _ = nested_glass_scene(rta.api, seed)
+    got = rta.probe(gw, rays)
+    want = oracle_probe(orc, ow, rays)
+    checked = 0
+    for g, w in zip(got, want):
+        if w is None:
+            continue
+        t, obj, c = w
+        assert g["t"] == t and g["object"] == obj
+        # n1/n2 are read only when the hit object is transparent (world.rs:128-129, 176-179)
+        assert (g["n1"], g["n2"]) == (c.n1, c.n2)
+        checked += 1
+    assert checked > 600
+
+
+def test_reference_known_answers_on_gpu(orc, rta):
+    """The reference's own world/camera tests, evaluated by the GPU path."""
+    api = rta.api
+    H = 1.0 / math.sqrt(2.0)
+    w = api.default_world()
+    c = rta.color_at(w, [[0, 0, -5, 0, 0, 1], [0, 0, -5, 0, 1, 0]])
+    assert np.allclose(c[0], (0.38066, 0.47583, 0.2855), atol=1e-5)  # world.rs:395-401
+    assert np.array_equal(c[1], (0, 0, 0))  # world.rs:387-393
+    w.object(0).set_ambient(1.0)
+    w.object(1).set_ambient(1.0)
+    assert np.allclose(rta.color_at(w, [[0, 0, 0.75, 0, 0, -1]])[0], (1, 1, 1), atol=1e-5)  # world.rs:403-429
+    # reflective floor (world.rs:490-506): shade_hit at the floor = color_at of the same ray
+    w = api.default_world()
+    w.add_object(api.plane().set_reflective(0.5).set_transform(api.m_translation(0, -1, 0)))
+    got = rta.color_at(w, [[0, 0, -3, 0, -H, H]])[0]
+    assert np.allclose(got, (0.87676, 0.92434, 0.82918), atol=1e-5)
+    # transparent floor over a red ball (world.rs:647-671) and with Schlick (world.rs:698-722)
+    for refl, want in [(0.0, (0.93642, 0.68642, 0.68642)), (0.5, (0.93391, 0.69643, 0.69243))]:
+        w = api.default_world()
+        fl = api.plane().set_transform(api.m_translation(0, -1, 0)).set_transparency(0.5).set_refractive_index(1.5)
+        fl.set_reflective(refl)
+        w.add_object(fl)
+        w.add_object(api.sphere().set_color(1, 0, 0).set_ambient(0.5).set_transform(api.m_translation(0, -3.5, -0.5)))
+        assert np.allclose(rta.color_at(w, [[0, 0, -3, 0, -H, H]])[0], want, atol=1e-5)
+    # camera.rs:241-302
+    cam = api.camera(201, 101, math.pi / 2)
+    assert np.allclose(rta.ray_for_pixel(cam, 100, 50), (0, 0, 0, 0, 0, -1), atol=1e-5)
+    assert np.allclose(rta.ray_for_pixel(cam, 0, 0), (0, 0, 0, 0.66519, 0.33259, -0.66851), atol=1e-5)
+    cam.set_transform(api.m_mul(api.m_rotation_y(math.pi / 4), api.m_translation(0, -2, 5)))
+    assert np.allclose(rta.ray_for_pixel(cam, 100, 50), (0, 2, -5, H, 0, -H), atol=1e-5)
+    cam = api.camera(11, 11, math.pi / 2)
+    cam.set_transform(api.m_view_transform((0, 0, -5), (0, 0, 0), (0, 1, 0)))
+    img, tracked = rta.parallel_render(cam, api.default_world())
+    assert np.allclose(img[5, 5], (0.38066, 0.47583, 0.2855), atol=1e-5)
+    assert tracked == 121  # the tracker ends at hsize * vsize (camera.rs:192)
+
+
+def test_primary_rays_bit_exact(orc, rta):
+    from ray_tracer_amd import scenes
+    for (h, v) in [(201, 101), (64, 64), (1000, 800), (37, 91)]:
+        _, gcam = scenes.default_scene(rta.api, h, v)
+        _, ocam = scenes.default_scene(orc.api, h, v)
+        rng = np.random.default_rng(h)
+        for _ in range(40):
+            x, y = int(rng.integers(0, h)), int(rng.integers(0, v))
+            assert np.array_equal(rta.ray_for_pixel(gcam, x, y), orc.ray_for_pixel(ocam, x, y))
+
+
+def frame_pair(orc, rta, scene_fn, depth=5, **kw):
+    gw, gcam = scene_fn(rta.api, **kw)
+    ow, ocam = scene_fn(orc.api, **kw)
+    gstats = {}
+    got = rta.render_rows(gcam, gw, depth=depth, stats=gstats)
+    cnt = [0, 0]
+    want = orc.parallel_render(ocam, ow, depth=depth, counters=cnt)
+    return got, want, gstats, cnt
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("default", dict(hsize=250, vsize=200)),
+    ("spheres_on_plane", dict(hsize=192, vsize=108)),
+    ("glass", dict(hsize=192, vsize=108)),
+    ("glass", dict(hsize=96, vsize=54, n_lights=4)),
+    ("random", dict(n_objects=300, hsize=160, vsize=90)),
+])
+def test_frame_matches_oracle(orc, rta, name, kw):
+    from ray_tracer_amd import scenes
+    got, want, gstats, cnt = frame_pair(orc, rta, scenes.SCENES[name], **kw)
+    err = np.abs(got - want).max()
+    assert err <= TOL, "%s: max |GPU - oracle| = %g" % (name, err)
+    # ray accounting: color_at and is_shadowed invocation counts agree exactly
+    assert gstats["color_rays"] == cnt[0] and gstats["shadow_rays"] == cnt[1]
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+@pytest.mark.parametrize("depth", [0, 1, 5])
+def test_frame_every_shape(orc, rta, kind, depth):
+    got, want, gstats, cnt = frame_pair(orc, rta, shapes_scene, depth=depth, kind=kind)
+    assert np.abs(got - want).max() <= TOL
+    assert gstats["color_rays"] == cnt[0] and gstats["shadow_rays"] == cnt[1]
+
+
+def test_color_at_batch_matches_oracle(orc, rta):
+    rng = np.random.default_rng(7)
+    rays = random_rays(rng, 4000, toward=(0, 0, 1))
+    gw, _ = shapes_scene(rta.api, kind=2)
+    ow, _ = shapes_scene(orc.api, kind=2)
+    gc, oc = [0, 0], [0, 0]
+    got = rta.color_at(gw, rays, remaining=5, counters=gc)
+    want = orc.color_at(ow, rays, remaining=5, counters=oc)
+    assert np.abs(got - want).max() <= TOL
+    assert gc == oc
+
+
+def test_row_tiles_and_chunks_agree(orc, rta):
+    """Rendering rows in separate calls, or with a workspace so small that the frame is split
+    into row chunks, gives the frame of a single call."""
+    from ray_tracer_amd import scenes
+    gw, gcam = scenes.glass_scene(rta.api, 120, 70)
+    whole = rta.render_rows(gcam, gw)
+    tiles = [rta.render_rows(gcam, gw, row_begin=a, row_end=b) for a, b in [(0, 10), (10, 33), (33, 70)]]
+    assert np.abs(np.concatenate(tiles) - whole).max() <= 1e-12
+    ctx = rta.Context()
+    ctx.set_workspace_limit(1 << 20)
+    scene = rta.Scene(ctx, rta.flatten(gw))
+    cd = rta.camera_desc(gcam)
+    out = np.empty((70, 120, 3))
+    st = rta.Stats()
+    rta._check(rta.rtx_render(ctx.h, scene.h, cd, 5, rta.F64, 0, 70, out.ctypes.data, out.nbytes, None, None, st))
+    assert st.n_chunks > 1
+    assert np.abs(out - whole).max() <= 1e-12
+    scene.close()
+    ctx.close()
+
+
+def test_f32_fast_path(orc, rta):
+    """f32 colours within 1/255 after 8-bit quantisation (src/scenes/canvas.rs:84-86) on at
+    least 99.9 % of the pixels, against the f64 oracle."""
+    from ray_tracer_amd import scenes
+    for name, kw in [("default", dict(hsize=400, vsize=320)), ("spheres_on_plane", dict(hsize=320, vsize=180)),
+                     ("glass", dict(hsize=320, vsize=180)), ("random", dict(n_objects=300, hsize=320, vsize=180))]:
+        gw, gcam = scenes.SCENES[name](rta.api, **kw)
+        ow, ocam = scenes.SCENES[name](orc.api, **kw)
+        got = rta.render_rows(gcam, gw, precision=rta.F32)
+        want = orc.parallel_render(ocam, ow)
+        q_got = orc.quantize_u8(got).astype(int)
+        q_want = orc.quantize_u8(want).astype(int)
+        ok = (np.abs(q_got - q_want).max(axis=2) <= 1).mean()
+        assert ok >= 0.999, "%s: only %.4f of the pixels within 1/255" % (name, ok)
+
+
+def test_edge_cases(orc, rta):
+    api = rta.api
+    # empty world: every pixel black, no light needed (nothing is ever hit)
+    w = api.world()
+    cam = api.camera(33, 17, 1.0)
+    assert not rta.render_rows(cam, w).any()
+    # objects but no light: the reference panics at lights[0] on the first hit (world.rs:123,147)
+    w.add_object(api.sphere())
+    with pytest.raises(Exception, match="light"):
+        rta.render_rows(cam, w)
+    w.add_light((-10, 10, -10))
+    # zero rows, one pixel, widths that are not a multiple of the 64-lane wave
+    assert rta.render_rows(cam, w, row_begin=5, row_end=5).shape == (0, 33, 3)
+    ow = orc.api.world()
+    ow.add_object(orc.api.sphere())
+    ow.add_light((-10, 10, -10))
+    for h, v in [(1, 1), (63, 3), (65, 2), (129, 5)]:
+        g = rta.render_rows(api.camera(h, v, 1.0), w)
+        o = orc.render_rows(orc.api.camera(h, v, 1.0), ow)
+        assert np.abs(g - o).max() <= TOL
+    # preview camera, depth 2 (camera.rs:203-222)
+    from ray_tracer_amd import scenes
+    gw, gcam = scenes.glass_scene(rta.api, 160, 120)
+    ow2, ocam = scenes.glass_scene(orc.api, 160, 120)
+    gp, op = gcam.preview(), ocam.preview()
+    assert gp.get()["hsize"] == op.get()["hsize"] == 533
+    g = rta.render_rows(gp, gw, depth=2, row_begin=100, row_end=140)
+    o = orc.render_rows(op, ow2, depth=2, row_begin=100, row_end=140)
+    assert np.abs(g - o).max() <= TOL
+
+
+def test_concurrent_renders_share_a_context(orc, rta):
+    """Preview and full render run concurrently from two host threads in the reference's GUI
+    (src/app.rs:96-110, 479-492)."""
+    from ray_tracer_amd import scenes
+    gw, gcam = scenes.glass_scene(rta.api, 200, 120)
+    expect_full = rta.render_rows(gcam, gw, depth=5)
+    expect_prev = rta.render_rows(gcam, gw, depth=2)
+    results = {}
+
+    def work(key, depth):
+        results[key] = [rta.render_rows(gcam, gw, depth=depth) for _ in range(4)]
+
+    threads = [threading.Thread(target=work, args=("full", 5)), threading.Thread(target=work, args=("prev", 2))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for img in results["full"]:
+        assert np.abs(img - expect_full).max() <= 1e-12
+    for img in results["prev"]:
+        assert np.abs(img - expect_prev).max() <= 1e-12
+
+
+def test_full_size_frame_properties(orc, rta):
+    """BASELINE size (3840x2160, default world): a random sample of pixels against the oracle's
+    color_at for the same primary rays, the ray counters against geometry, and the frame
+    against its own row tiles."""
+    from ray_tracer_amd import scenes
+    gw, gcam = scenes.default_scene(rta.api, 3840, 2160)
+    ow, ocam = scenes.default_scene(orc.api, 3840, 2160)
+    st = {}
+    img = rta.render_rows(gcam, gw, stats=st)
+    assert st["color_rays"] == 3840 * 2160
+    lit = np.count_nonzero(img.sum(axis=2))
+    assert st["shadow_rays"] == lit  # every hit of the default world has a non-black ambient term
+    rng = np.random.default_rng(11)
+    ys, xs = rng.integers(0, 2160, 3000), rng.integers(0, 3840, 3000)
+    # sample densely where the spheres are (image centre) as well
+    ys[:1500] = rng.integers(900, 1300, 1500)
+    xs[:1500] = rng.integers(1500, 2340, 1500)
+    rays = np.array([orc.ray_for_pixel(ocam, int(x), int(y)) for x, y in zip(xs, ys)])
+    want = orc.color_at(ow, rays)
+    assert np.abs(img[ys, xs] - want).max() <= TOL
+    assert np.count_nonzero(want.sum(axis=1)) > 200
+    band = rta.render_rows(gcam, gw, row_begin=1070, row_end=1090)
+    assert np.array_equal(band, img[1070:1090])
+    # left-right mirror symmetry of the scene and camera is not exact in floating point, but the
+    # set of lit pixels per row is symmetric to within one pixel
+    mask = img.sum(axis=2) > 0
+    assert np.abs(mask.sum(axis=1) - mask[:, ::-1].sum(axis=1)).max() == 0
