@@ -237,7 +237,7 @@ uint64_t level_growth(uint32_t sf, uint32_t level)
 
 struct FramePlan {
     uint32_t levels = 0;         // bounce launches per chunk
-    uint64_t cap[2] = { 0, 0 };  // entries per primary ray in the odd / even level queue
+    uint64_t cap_odd = 0, cap_even = 0;  // worst-case entries per primary ray in the queue of odd / even levels
     uint64_t chunk_pix = 0;      // primary rays per chunk
 };
 
@@ -249,14 +249,17 @@ int plan_frame(const rtx_context *ctx, uint32_t sf, uint32_t max_depth, uint64_t
     if (max_depth >= kMaxLevels) return fail(RTX_ERR_INVALID, "max_depth %u is not supported (limit %u)", max_depth, kMaxLevels - 1);
     const bool secondary = (sf & (SF_REFLECTIVE | SF_TRANSPARENT)) != 0 && max_depth > 0;
     p->levels = secondary ? max_depth : 0;
-    p->cap[0] = p->cap[1] = 0;
-    for (uint32_t L = 1; L <= p->levels; ++L) p->cap[L & 1] = std::max(p->cap[L & 1], level_growth(sf, L));
-    const uint64_t per_pix = (p->cap[0] + p->cap[1]) * 8 * sizeof(R);
+    p->cap_odd = p->cap_even = 0;
+    for (uint32_t L = 1; L <= p->levels; ++L) {
+        uint64_t &cap = (L & 1) ? p->cap_odd : p->cap_even;
+        cap = std::max(cap, level_growth(sf, L));
+    }
+    const uint64_t per_pix = (p->cap_odd + p->cap_even) * 8 * sizeof(R);
     uint64_t chunk = n_pix;
     if (per_pix) {
         chunk = std::min<uint64_t>(chunk, ctx->workspace_limit / per_pix);
         // queue slots are indexed with 32 bits
-        chunk = std::min<uint64_t>(chunk, 0xfffffff0ull / std::max(p->cap[0], p->cap[1]));
+        chunk = std::min<uint64_t>(chunk, 0xfffffff0ull / std::max(p->cap_odd, p->cap_even));
     }
     chunk = std::min<uint64_t>(chunk, 0x7fffff00ull);
     if (align > 1) chunk = (chunk / align) * align;
@@ -275,8 +278,8 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Slot *slot, hipStrea
     int rc = plan_frame<R>(ctx, scene->sf, max_depth, n_pix, align, &plan);
     if (rc) return rc;
     const uint32_t n_chunks = (uint32_t)((n_pix + plan.chunk_pix - 1) / plan.chunk_pix);
-    const uint64_t cap0 = plan.cap[0] * plan.chunk_pix, cap1 = plan.cap[1] * plan.chunk_pix;
-    rc = grow(&slot->queues, &slot->queue_bytes, (size_t)((cap0 + cap1) * 8 * sizeof(R)));
+    const uint64_t cap_odd = plan.cap_odd * plan.chunk_pix, cap_even = plan.cap_even * plan.chunk_pix;
+    rc = grow(&slot->queues, &slot->queue_bytes, (size_t)((cap_odd + cap_even) * 8 * sizeof(R)));
     if (rc) return rc;
     const size_t counts_need = (size_t)n_chunks * (kMaxLevels + 1);
     if (counts_need > slot->counts_n) {
@@ -290,7 +293,7 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Slot *slot, hipStrea
     HIP_TRY(hipMemsetAsync(slot->shards, 0, sizeof(StatShard) * kStatShards, stream));
 
     R *q_odd = (R *)slot->queues;
-    R *q_even = q_odd + cap0 * 8;
+    R *q_even = q_odd + cap_odd * 8;
     CameraDev<R> cam_zero;
     std::memset(&cam_zero, 0, sizeof cam_zero);
     const SceneDev<R> &S = scene_dev<R>(scene);
@@ -304,7 +307,7 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Slot *slot, hipStrea
             QueueDev<R> q;
             q.rec = (level & 1) ? q_odd : q_even;
             q.count = counts + level;
-            q.capacity = (uint32_t)((level & 1) ? cap0 : cap1);
+            q.capacity = (uint32_t)((level & 1) ? cap_odd : cap_even);
             q.pad = 0;
             if (level > plan.levels) q.capacity = 0;
             return q;
