@@ -8,7 +8,8 @@ PKG="ray-tracer_amd"
 OUT="$PKG/lib"
 mkdir -p "$OUT" "$PKG/build"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-COMMON="-O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
+COMMON="-O3 -std=c++17 -fPIC -Wall -Wno-unused-function ${RTX_EXTRA_FLAGS:-}"
+LIBNAME="${RTX_LIBNAME:-librtx.so}"
 if [[ "$what" == "lib" || "$what" == "all" ]]; then
   # f64 parity kernels: no FMA contraction; f32 kernels: contraction on
   "$HIPCC" --offload-arch=gfx950 $COMMON -ffp-contract=off -c "$PKG/csrc/render_f64.hip" -o "$PKG/build/render_f64.o" &
@@ -17,9 +18,9 @@ if [[ "$what" == "lib" || "$what" == "all" ]]; then
   g++ $COMMON -ffp-contract=off -fno-fast-math -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -c "$PKG/host/rt.cpp" -o "$PKG/build/rt.o" &
   g++ $COMMON -ffp-contract=off -fno-fast-math -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -c "$PKG/host/rt_capi.cpp" -o "$PKG/build/rt_capi.o" &
   wait
-  "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/librtx.so" "$PKG/build/render_f64.o" "$PKG/build/render_f32.o" \
+  "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/$LIBNAME" "$PKG/build/render_f64.o" "$PKG/build/render_f32.o" \
       "$PKG/build/rtx_api.o" "$PKG/build/rt.o" "$PKG/build/rt_capi.o"
-  echo "built $OUT/librtx.so"
+  echo "built $OUT/$LIBNAME"
 fi
 if [[ "$what" == "oracle" || "$what" == "all" ]]; then
   gcc -std=gnu11 -O2 -ffp-contract=off -fno-fast-math -Wall -fPIC -shared -pthread oracle/rt_oracle.c -o oracle/liboracle.so -lm

@@ -15,7 +15,8 @@ from .scene_api import (AMBIENT, CHECKER3D, CONE, CUBE, CYLINDER, DIFFUSE, F32, 
                         TRANSPARENCY, Panic, SceneAPI)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librtx.so")
+# RTX_LIB selects an alternative build of the library (kernel tuning experiments)
+LIB_PATH = os.environ.get("RTX_LIB") or os.path.join(_HERE, "lib", "librtx.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError("%s is missing: build it with ./build.sh (python -c 'import __graft_entry__ as g; g.build()')"

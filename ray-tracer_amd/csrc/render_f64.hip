@@ -19,7 +19,7 @@ k_probe(SceneDev<double> S, const double *__restrict__ rays, uint32_t n, rtx_pro
     for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < n; k += stride) {
         const double *r = rays + (size_t)k * 6;
         V3<double> ro = { r[0], r[1], r[2] }, rd = { r[3], r[4], r[5] };
-        Node<double> nd = trace_node<double, SF>(S, ro, rd, 5u);
+        Node<double> nd = trace_node<double, SF, false>(S, nullptr, ro, rd, 5u);
         rtx_probe p;
         __builtin_memset(&p, 0, sizeof p);
         p.t = -1.0;

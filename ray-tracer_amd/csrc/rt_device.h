@@ -17,6 +17,12 @@
 #include "rt_types.h"
 
 #define RT_DEV __device__ __forceinline__
+// Table walks may fetch record i+1 while record i is in use.  That doubles the scalar registers
+// a record occupies, and the spills this causes cost more than the latency it hides (measured:
+// 83 -> 70 us on the default 4K frame, 364 -> 324 ms on the 10k-object scene), so it is off.
+#ifndef RTX_WALK_PREFETCH
+#define RTX_WALK_PREFETCH 0
+#endif
 
 namespace rtx {
 
@@ -54,7 +60,7 @@ template <typename R> RT_DEV R dot3(V3<R> a, V3<R> b) { return (a.x * b.x + a.y 
 // src/matrices/tuples.rs:58-73: magnitude, then three divisions
 template <typename R> RT_DEV V3<R> normalize3(V3<R> a)
 {
-    R mag = Num<R>::sqrt_((a.x * a.x + a.y * a.y) + a.z * a.z);
+    const R mag = Num<R>::sqrt_((a.x * a.x + a.y * a.y) + a.z * a.z);
     return { Num<R>::div(a.x, mag), Num<R>::div(a.y, mag), Num<R>::div(a.z, mag) };
 }
 // src/matrices/matrix4.rs:172-193 for a point (w = 1) and a vector (w = 0); m = 3 rows x 4
@@ -73,53 +79,51 @@ template <typename R> RT_DEV V3<R> xform_vector(const R *m, V3<R> v)
 
 // ---- ray/object intersection in object space -----------------------------------------
 // Each routine calls emit(t) once per intersection, in the order the reference pushes them.
+// Terms that depend on the ray origin alone (`c` of the quadratics, the slab numerators of
+// the cube) come in as arguments: a secondary ray computes them per lane, while primary rays
+// -- which all start at the camera -- read them from a table built once per frame.
 
-// src/shapes/spheres.rs:24-42
-template <typename R, typename Emit> RT_DEV void isect_sphere(V3<R> o, V3<R> d, Emit &&emit)
+// src/shapes/spheres.rs:24-42; c = (origin . origin) - 1
+template <typename R, typename Emit> RT_DEV void isect_sphere(V3<R> o, V3<R> d, R c, Emit &&emit)
 {
     R a = dot3(d, d);
     R b = R(2) * dot3(d, o);
-    R c = dot3(o, o) - R(1);
     R disc = b * b - ((R(4) * a) * c);
     if (!(disc < R(0))) {
         R sq = Num<R>::sqrt_(disc);
         R two_a = R(2) * a;
-        R t1 = Num<R>::div(-b - sq, two_a);
-        R t2 = Num<R>::div(-b + sq, two_a);
-        emit(t1);
-        emit(t2);
+        emit(Num<R>::div(-b - sq, two_a));
+        emit(Num<R>::div(-b + sq, two_a));
     }
 }
-// src/shapes/planes.rs:11-17
-template <typename R, typename Emit> RT_DEV void isect_plane(V3<R> o, V3<R> d, Emit &&emit)
+// src/shapes/planes.rs:11-17; neg_oy = -origin.y
+template <typename R, typename Emit> RT_DEV void isect_plane(R neg_oy, R dy, Emit &&emit)
 {
-    if (!(Num<R>::abs_(d.y) < Num<R>::eps)) emit(Num<R>::div(-o.y, d.y));
+    if (!(Num<R>::abs_(dy) < Num<R>::eps)) emit(Num<R>::div(neg_oy, dy));
 }
-// src/shapes/cubes.rs:31-51
-template <typename R> RT_DEV void cube_axis(R origin, R direction, R &tmin, R &tmax)
+// src/shapes/cubes.rs:31-51; lo_num = -1 - origin, hi_num = 1 - origin
+template <typename R> RT_DEV void cube_axis(R lo_num, R hi_num, R direction, R &tmin, R &tmax)
 {
-    R tmin_num = R(-1) - origin;
-    R tmax_num = R(1) - origin;
     R lo, hi;
     if (!(Num<R>::abs_(direction) < Num<R>::eps)) {
-        lo = Num<R>::div(tmin_num, direction);
-        hi = Num<R>::div(tmax_num, direction);
+        lo = Num<R>::div(lo_num, direction);
+        hi = Num<R>::div(hi_num, direction);
     } else {
-        lo = tmin_num * Num<R>::big;
-        hi = tmax_num * Num<R>::big;
+        lo = lo_num * Num<R>::big;
+        hi = hi_num * Num<R>::big;
     }
     if (lo > hi) { R tmp = lo; lo = hi; hi = tmp; }
     tmin = lo;
     tmax = hi;
 }
 // src/shapes/cubes.rs:7-29
-template <typename R, typename Emit> RT_DEV void isect_cube(V3<R> o, V3<R> d, Emit &&emit)
+template <typename R, typename Emit> RT_DEV void isect_cube(V3<R> lo_num, V3<R> hi_num, V3<R> d, Emit &&emit)
 {
     R xtmin, xtmax, ytmin, ytmax, ztmin, ztmax;
-    cube_axis(o.x, d.x, xtmin, xtmax);
-    cube_axis(o.y, d.y, ytmin, ytmax);
+    cube_axis(lo_num.x, hi_num.x, d.x, xtmin, xtmax);
+    cube_axis(lo_num.y, hi_num.y, d.y, ytmin, ytmax);
     if (ytmin > xtmax || xtmin > ytmax) return;
-    cube_axis(o.z, d.z, ztmin, ztmax);
+    cube_axis(lo_num.z, hi_num.z, d.z, ztmin, ztmax);
     R tmin = Num<R>::max_(Num<R>::max_(xtmin, ytmin), ztmin);
     R tmax = Num<R>::min_(Num<R>::min_(xtmax, ytmax), ztmax);
     if (tmin > tmax) return;
@@ -164,33 +168,31 @@ RT_DEV bool isect_wall(R a, R b, R c, V3<R> o, V3<R> d, R ymin, R ymax, Emit &&e
     if (ymin < y1 && y1 < ymax) emit(t1);
     return true;
 }
-// src/shapes/cylinders.rs:27-64
+// src/shapes/cylinders.rs:27-64; o2 = 2 * origin, c = origin.x^2 + origin.z^2 - 1
 template <typename R, typename Emit>
-RT_DEV void isect_cylinder(V3<R> o, V3<R> d, R ymin, R ymax, bool closed, Emit &&emit)
+RT_DEV void isect_cylinder(V3<R> o, V3<R> o2, R c, V3<R> d, R ymin, R ymax, bool closed, Emit &&emit)
 {
     R a = d.x * d.x + d.z * d.z;
     if (a < Num<R>::eps) {
         isect_caps<R, false>(o, d, ymin, ymax, closed, emit);
         return;
     }
-    R b = (R(2) * o.x) * d.x + (R(2) * o.z) * d.z;
-    R c = (o.x * o.x + o.z * o.z) - R(1);
+    R b = o2.x * d.x + o2.z * d.z;
     if (!isect_wall(a, b, c, o, d, ymin, ymax, emit)) return;
     isect_caps<R, false>(o, d, ymin, ymax, closed, emit);
 }
-// src/shapes/cones.rs:27-82
+// src/shapes/cones.rs:27-82; o2 = 2 * origin, c = origin.x^2 - origin.y^2 + origin.z^2
 template <typename R, typename Emit>
-RT_DEV void isect_cone(V3<R> o, V3<R> d, R ymin, R ymax, bool closed, Emit &&emit)
+RT_DEV void isect_cone(V3<R> o, V3<R> o2, R c, V3<R> d, R ymin, R ymax, bool closed, Emit &&emit)
 {
     R a = (d.x * d.x - d.y * d.y) + d.z * d.z;
-    R b = ((R(2) * o.x) * d.x - (R(2) * o.y) * d.y) + (R(2) * o.z) * d.z;
+    R b = (o2.x * d.x - o2.y * d.y) + o2.z * d.z;
     bool a0 = Num<R>::abs_(a) < Num<R>::eps;
     bool b0 = Num<R>::abs_(b) < Num<R>::eps;
     if (a0 && b0) {
         isect_caps<R, true>(o, d, ymin, ymax, closed, emit);
         return;
     }
-    R c = (o.x * o.x - o.y * o.y) + o.z * o.z;
     if (a0) {
         emit(Num<R>::div(-c, R(2) * b));
         isect_caps<R, true>(o, d, ymin, ymax, closed, emit);
@@ -199,108 +201,278 @@ RT_DEV void isect_cone(V3<R> o, V3<R> d, R ymin, R ymax, bool closed, Emit &&emi
     if (!isect_wall(a, b, c, o, d, ymin, ymax, emit)) return;
     isect_caps<R, true>(o, d, ymin, ymax, closed, emit);
 }
+// the origin-only terms, as the reference's expressions evaluate them
+template <typename R> RT_DEV R sphere_c(V3<R> o) { return dot3(o, o) - R(1); }
+template <typename R> RT_DEV R cylinder_c(V3<R> o) { return (o.x * o.x + o.z * o.z) - R(1); }
+template <typename R> RT_DEV R cone_c(V3<R> o) { return (o.x * o.x - o.y * o.y) + o.z * o.z; }
+template <typename R> RT_DEV V3<R> twice(V3<R> o) { return { R(2) * o.x, R(2) * o.y, R(2) * o.z }; }
 
-// src/shapes/objects.rs:185-198 with src/rays.rs:30-34: ray into object space (direction not
-// renormalised), then the per-shape routine.  `rec` is addressed with a wave-uniform index.
-template <typename R, typename Emit>
-RT_DEV void isect_object(const HotRec<R> &rec, V3<R> ro, V3<R> rd, Emit &&emit)
+// ---- walking the object tables ---------------------------------------------------------
+// Visit records 0..n-1 of one table with a wave-uniform index: the records travel through
+// the scalar cache into SGPRs, and the other waves of the SIMD cover the fetch latency.
+template <typename Rec, typename Body>
+RT_DEV void walk_table(const Rec *__restrict__ recs, uint32_t n, uint32_t slot0, Body &&body)
 {
-    const uint32_t type = rec.type;
-    if (type == SH_PLANE) {
+#if RTX_WALK_PREFETCH
+    if (n == 0) return;
+    Rec cur = recs[0];
+    for (uint32_t i = 0; i < n; ++i) {
+        const Rec nxt = recs[(i + 1 < n) ? i + 1 : i];
+        body(cur, slot0 + i);
+        cur = nxt;
+    }
+#else
+    for (uint32_t i = 0; i < n; ++i) body(recs[i], slot0 + i);
+#endif
+}
+
+// Object::intersect for every object of the world (src/shapes/objects.rs:185-198 with
+// src/rays.rs:30-34): the ray goes into object space (direction not renormalised), then the
+// per-shape routine runs.  For each object `per(slot, run)` is called once; `run(emit)`
+// performs the intersection and calls emit(t) per intersection.
+template <typename R, typename Per>
+RT_DEV void walk_scene(const SceneDev<R> &S, V3<R> ro, V3<R> rd, Per &&per)
+{
+    uint32_t slot0 = 0;
+    walk_table(S.sph, S.n_sph, slot0, [&](const XformRec<R> &rec, uint32_t slot) {
+        const V3<R> o = xform_point(rec.m, ro);
+        const V3<R> d = xform_vector(rec.m, rd);
+        per(slot, [&](auto &&emit) { isect_sphere(o, d, sphere_c(o), emit); });
+    });
+    slot0 += S.n_sph;
+    walk_table(S.pln, S.n_pln, slot0, [&](const PlaneRec<R> &rec, uint32_t slot) {
         // only the y row of the object-space ray is read by planes.rs:11-17
-        V3<R> o = { R(0), ((rec.inv[4] * ro.x + rec.inv[5] * ro.y) + rec.inv[6] * ro.z) + rec.inv[7], R(0) };
-        V3<R> d = { R(0), (rec.inv[4] * rd.x + rec.inv[5] * rd.y) + rec.inv[6] * rd.z, R(0) };
-        isect_plane(o, d, emit);
+        const R oy = ((rec.m[0] * ro.x + rec.m[1] * ro.y) + rec.m[2] * ro.z) + rec.m[3];
+        const R dy = (rec.m[0] * rd.x + rec.m[1] * rd.y) + rec.m[2] * rd.z;
+        per(slot, [&](auto &&emit) { isect_plane(-oy, dy, emit); });
+    });
+    slot0 += S.n_pln;
+    walk_table(S.cub, S.n_cub, slot0, [&](const XformRec<R> &rec, uint32_t slot) {
+        const V3<R> o = xform_point(rec.m, ro);
+        const V3<R> d = xform_vector(rec.m, rd);
+        const V3<R> lo = { R(-1) - o.x, R(-1) - o.y, R(-1) - o.z };
+        const V3<R> hi = { R(1) - o.x, R(1) - o.y, R(1) - o.z };
+        per(slot, [&](auto &&emit) { isect_cube(lo, hi, d, emit); });
+    });
+    slot0 += S.n_cub;
+    walk_table(S.cyl, S.n_cyl, slot0, [&](const CappedRec<R> &rec, uint32_t slot) {
+        const V3<R> o = xform_point(rec.m, ro);
+        const V3<R> d = xform_vector(rec.m, rd);
+        per(slot, [&](auto &&emit) { isect_cylinder(o, twice(o), cylinder_c(o), d, rec.ymin, rec.ymax, rec.closed != 0, emit); });
+    });
+    slot0 += S.n_cyl;
+    walk_table(S.con, S.n_con, slot0, [&](const CappedRec<R> &rec, uint32_t slot) {
+        const V3<R> o = xform_point(rec.m, ro);
+        const V3<R> d = xform_vector(rec.m, rd);
+        per(slot, [&](auto &&emit) { isect_cone(o, twice(o), cone_c(o), d, rec.ymin, rec.ymax, rec.closed != 0, emit); });
+    });
+}
+
+// The same walk for primary rays: they all start at the camera, so the object-space origin
+// and every term derived from it alone were evaluated once per object (k_primary_tables,
+// with the expressions above) and are read here as wave-uniform scalars.
+template <typename R> RT_DEV V3<R> xform_vector9(const R *m, V3<R> v)
+{
+    return { (m[0] * v.x + m[1] * v.y) + m[2] * v.z,
+             (m[3] * v.x + m[4] * v.y) + m[5] * v.z,
+             (m[6] * v.x + m[7] * v.y) + m[8] * v.z };
+}
+template <typename R, typename Per>
+RT_DEV void walk_scene_primary(const PrimScene<R> &P, V3<R> rd, Per &&per)
+{
+    uint32_t slot0 = 0;
+    walk_table(P.sph, P.n_sph, slot0, [&](const PrimSphereRec<R> &rec, uint32_t slot) {
+        const V3<R> o = { rec.o[0], rec.o[1], rec.o[2] };
+        const V3<R> d = xform_vector9(rec.m, rd);
+        per(slot, [&](auto &&emit) { isect_sphere(o, d, rec.c, emit); });
+    });
+    slot0 += P.n_sph;
+    walk_table(P.pln, P.n_pln, slot0, [&](const PrimPlaneRec<R> &rec, uint32_t slot) {
+        const R dy = (rec.m[0] * rd.x + rec.m[1] * rd.y) + rec.m[2] * rd.z;
+        per(slot, [&](auto &&emit) { isect_plane(rec.neg_oy, dy, emit); });
+    });
+    slot0 += P.n_pln;
+    walk_table(P.cub, P.n_cub, slot0, [&](const PrimCubeRec<R> &rec, uint32_t slot) {
+        const V3<R> d = xform_vector9(rec.m, rd);
+        const V3<R> lo = { rec.lo[0], rec.lo[1], rec.lo[2] };
+        const V3<R> hi = { rec.hi[0], rec.hi[1], rec.hi[2] };
+        per(slot, [&](auto &&emit) { isect_cube(lo, hi, d, emit); });
+    });
+    slot0 += P.n_cub;
+    walk_table(P.cyl, P.n_cyl, slot0, [&](const PrimCappedRec<R> &rec, uint32_t slot) {
+        const V3<R> o = { rec.o[0], rec.o[1], rec.o[2] };
+        const V3<R> o2 = { rec.o2[0], rec.o2[1], rec.o2[2] };
+        const V3<R> d = xform_vector9(rec.m, rd);
+        per(slot, [&](auto &&emit) { isect_cylinder(o, o2, rec.c, d, rec.ymin, rec.ymax, rec.closed != 0, emit); });
+    });
+    slot0 += P.n_cyl;
+    walk_table(P.con, P.n_con, slot0, [&](const PrimCappedRec<R> &rec, uint32_t slot) {
+        const V3<R> o = { rec.o[0], rec.o[1], rec.o[2] };
+        const V3<R> o2 = { rec.o2[0], rec.o2[1], rec.o2[2] };
+        const V3<R> d = xform_vector9(rec.m, rd);
+        per(slot, [&](auto &&emit) { isect_cone(o, o2, rec.c, d, rec.ymin, rec.ymax, rec.closed != 0, emit); });
+    });
+}
+
+// Fill the primary-ray table entry of one slot from the scene tables and the camera origin.
+template <typename R, typename Rec> RT_DEV void copy3x3(const R *m, Rec &out)
+{
+    for (int r = 0; r < 3; ++r)
+        for (int k = 0; k < 3; ++k) out.m[r * 3 + k] = m[r * 4 + k];
+}
+template <typename R>
+RT_DEV void make_primary_record(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> cam_origin, uint32_t slot)
+{
+    uint32_t i = slot;
+    if (i < S.n_sph) {
+        PrimSphereRec<R> out;
+        copy3x3(S.sph[i].m, out);
+        const V3<R> o = xform_point(S.sph[i].m, cam_origin);
+        out.o[0] = o.x; out.o[1] = o.y; out.o[2] = o.z;
+        out.c = sphere_c(o);
+        out.pad = R(0);
+        const_cast<PrimSphereRec<R> *>(P.sph)[i] = out;
         return;
     }
-    V3<R> o = xform_point(rec.inv, ro);
-    V3<R> d = xform_vector(rec.inv, rd);
-    if (type == SH_SPHERE) isect_sphere(o, d, emit);
-    else if (type == SH_CUBE) isect_cube(o, d, emit);
-    else if (type == SH_CYLINDER) isect_cylinder(o, d, rec.ymin, rec.ymax, (rec.flags & OF_CLOSED) != 0, emit);
-    else isect_cone(o, d, rec.ymin, rec.ymax, (rec.flags & OF_CLOSED) != 0, emit);
+    i -= S.n_sph;
+    if (i < S.n_pln) {
+        PrimPlaneRec<R> out;
+        const R *m = S.pln[i].m;
+        out.m[0] = m[0]; out.m[1] = m[1]; out.m[2] = m[2];
+        out.neg_oy = -(((m[0] * cam_origin.x + m[1] * cam_origin.y) + m[2] * cam_origin.z) + m[3]);
+        const_cast<PrimPlaneRec<R> *>(P.pln)[i] = out;
+        return;
+    }
+    i -= S.n_pln;
+    if (i < S.n_cub) {
+        PrimCubeRec<R> out;
+        copy3x3(S.cub[i].m, out);
+        const V3<R> o = xform_point(S.cub[i].m, cam_origin);
+        out.lo[0] = R(-1) - o.x; out.lo[1] = R(-1) - o.y; out.lo[2] = R(-1) - o.z;
+        out.hi[0] = R(1) - o.x; out.hi[1] = R(1) - o.y; out.hi[2] = R(1) - o.z;
+        out.pad = R(0);
+        const_cast<PrimCubeRec<R> *>(P.cub)[i] = out;
+        return;
+    }
+    i -= S.n_cub;
+    const bool is_cyl = i < S.n_cyl;
+    if (!is_cyl) i -= S.n_cyl;
+    if (!is_cyl && i >= S.n_con) return;
+    const CappedRec<R> &src = is_cyl ? S.cyl[i] : S.con[i];
+    PrimCappedRec<R> out;
+    copy3x3(src.m, out);
+    const V3<R> o = xform_point(src.m, cam_origin);
+    const V3<R> o2 = twice(o);
+    out.o[0] = o.x; out.o[1] = o.y; out.o[2] = o.z;
+    out.o2[0] = o2.x; out.o2[1] = o2.y; out.o2[2] = o2.z;
+    out.c = is_cyl ? cylinder_c(o) : cone_c(o);
+    out.ymin = src.ymin; out.ymax = src.ymax; out.closed = src.closed;
+    for (auto &w : out.pad) w = 0;
+    const_cast<PrimCappedRec<R> *>(is_cyl ? P.cyl : P.con)[i] = out;
 }
 
 // ---- closest hit over the whole world ---------------------------------------------------
 // The reference concatenates every object's intersections, stable-sorts by t and takes the
-// first t >= 0 (src/scenes/world.rs:98-119).  Equivalent single pass: the smallest t >= 0,
-// the lowest object index winning ties (strict '<' while walking objects in order).
+// first t >= 0 (src/scenes/world.rs:98-119): the smallest t >= 0, and among equal t the object
+// that comes first in World.objects.  The tables are walked shape by shape, so a tie between
+// two objects is settled by looking up their World indices (rare path).
 //
 // With TRACK the same pass also derives n1/n2 of prepare_computations
 // (world.rs:253-285).  Everything that precedes the hit in the sorted list has t < 0.  An
 // object sits in `containers` at the hit iff it has an odd number of negative t's, and the
-// list is ordered by each object's largest negative t (ties: object order).  Only the last
+// list is ordered by each object's largest negative t (ties: World order).  Only the last
 // entry and, when the hit object itself is that entry, the one before it are ever read, so
 // the two "latest" open objects are all that must be remembered.
 template <typename R>
 struct Hit {
     R t;
-    uint32_t obj;      // 0xffffffff = miss
+    uint32_t slot;     // 0xffffffff = miss
+    uint32_t obj;      // index in World.objects (valid when slot is)
     bool hit_open;     // TRACK: the hit object is in `containers` before it is toggled
     R top1_t, top2_t;  // TRACK: largest negative t of the last / second-to-last container
-    uint32_t top1, top2;
+    uint32_t top1, top2;  // TRACK: their slots
 };
 
-template <typename R, bool TRACK>
-RT_DEV Hit<R> closest_hit(const SceneDev<R> &S, V3<R> ro, V3<R> rd)
+constexpr uint32_t kNone = 0xffffffffu;
+
+template <typename R, bool TRACK, typename Walk>
+RT_DEV Hit<R> closest_hit_with(const SceneDev<R> &S, Walk &&walk)
 {
     Hit<R> h;
     h.t = Num<R>::inf;
-    h.obj = 0xffffffffu;
+    h.slot = kNone;
+    h.obj = kNone;
     h.hit_open = false;
-    h.top1 = h.top2 = 0xffffffffu;
+    h.top1 = h.top2 = kNone;
     h.top1_t = h.top2_t = -Num<R>::inf;
-    for (uint32_t i = 0; i < S.n; ++i) {
-        const HotRec<R> &rec = S.hot[i];
+    // true when `slot` precedes `other` in World.objects
+    auto before = [&](uint32_t slot, uint32_t other) { return S.slot_obj[slot] < S.slot_obj[other]; };
+    walk([&](uint32_t slot, auto &&run) {
         if constexpr (!TRACK) {
-            isect_object(rec, ro, rd, [&](R t) {
-                if (t >= R(0) && t < h.t) { h.t = t; h.obj = i; }
+            run([&](R t) {
+                if (t >= R(0) && t <= h.t) {
+                    if (t < h.t || h.slot == kNone || (h.slot != slot && before(slot, h.slot))) { h.t = t; h.slot = slot; }
+                }
             });
         } else {
             R best = Num<R>::inf;       // smallest t >= 0 of this object
             R last_neg = -Num<R>::inf;  // largest t < 0 of this object
             uint32_t n_neg = 0;
-            isect_object(rec, ro, rd, [&](R t) {
-                if (t >= R(0)) best = Num<R>::min_(best, t);
+            bool any_pos = false;
+            run([&](R t) {
+                if (t >= R(0)) { best = Num<R>::min_(best, t); any_pos = true; }
                 else if (t < R(0)) { n_neg++; last_neg = Num<R>::max_(last_neg, t); }
             });
-            const bool open = (n_neg & 1u) && (rec.flags & OF_CONTAINER);
-            if (best < h.t) { h.t = best; h.obj = i; h.hit_open = open; }
+            bool open = false;
+            if (n_neg & 1u) open = (S.cold[S.slot_obj[slot]].flags & OF_CONTAINER) != 0;
+            if (any_pos && best <= h.t) {
+                if (best < h.t || h.slot == kNone || before(slot, h.slot)) { h.t = best; h.slot = slot; h.hit_open = open; }
+            }
             if (open) {
-                // later in the sorted list = larger t, or equal t and higher object index
-                if (last_neg >= h.top1_t) {
+                // later in the sorted list = larger t, or equal t and later in World.objects
+                const bool after1 = last_neg > h.top1_t || (last_neg == h.top1_t && (h.top1 == kNone || before(h.top1, slot)));
+                if (after1) {
                     h.top2 = h.top1; h.top2_t = h.top1_t;
-                    h.top1 = i; h.top1_t = last_neg;
-                } else if (last_neg >= h.top2_t) {
-                    h.top2 = i; h.top2_t = last_neg;
+                    h.top1 = slot; h.top1_t = last_neg;
+                } else {
+                    const bool after2 = last_neg > h.top2_t || (last_neg == h.top2_t && (h.top2 == kNone || before(h.top2, slot)));
+                    if (after2) { h.top2 = slot; h.top2_t = last_neg; }
                 }
             }
         }
-    }
+    });
+    if (h.slot != kNone) h.obj = S.slot_obj[h.slot];
     return h;
+}
+template <typename R, bool TRACK>
+RT_DEV Hit<R> closest_hit(const SceneDev<R> &S, V3<R> ro, V3<R> rd)
+{
+    return closest_hit_with<R, TRACK>(S, [&](auto &&per) { walk_scene(S, ro, rd, per); });
+}
+template <typename R, bool TRACK>
+RT_DEV Hit<R> closest_hit_primary(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> rd)
+{
+    return closest_hit_with<R, TRACK>(S, [&](auto &&per) { walk_scene_primary(P, rd, per); });
 }
 
 // src/scenes/world.rs:146-158.  shadowed iff the closest hit (t >= 0) lies before the light
 // and its object casts a shadow.  When every object casts, any hit with 0 <= t < distance
 // decides it, so the walk needs no closest-hit bookkeeping.
 template <typename R, uint32_t SF>
-RT_DEV bool is_shadowed(const SceneDev<R> &S, V3<R> p)
+RT_DEV bool is_shadowed(const SceneDev<R> &S, V3<R> p, V3<R> dir, R distance)
 {
-    V3<R> v = { S.light_pos[0] - p.x, S.light_pos[1] - p.y, S.light_pos[2] - p.z };
-    R distance = Num<R>::sqrt_((v.x * v.x + v.y * v.y) + v.z * v.z);
-    V3<R> dir = { Num<R>::div(v.x, distance), Num<R>::div(v.y, distance), Num<R>::div(v.z, distance) };
     if constexpr ((SF & SF_ALL_CAST) != 0) {
         bool shadowed = false;
-        for (uint32_t i = 0; i < S.n; ++i) {
-            isect_object(S.hot[i], p, dir, [&](R t) {
+        walk_scene(S, p, dir, [&](uint32_t, auto &&run) {
+            run([&](R t) {
                 if (t >= R(0) && t < distance) shadowed = true;
             });
-        }
+        });
         return shadowed;
     } else {
         Hit<R> h = closest_hit<R, false>(S, p, dir);
-        if (h.obj == 0xffffffffu) return false;
-        return h.t < distance && (S.hot[h.obj].flags & OF_CASTS_SHADOW) != 0;
+        if (h.slot == kNone) return false;
+        return h.t < distance && (S.cold[h.obj].flags & OF_CASTS_SHADOW) != 0;
     }
 }
 
@@ -380,28 +552,29 @@ struct Node {
     R refract_factor;     // transparency [* (1 - schlick)]
 };
 
-template <typename R, uint32_t SF>
-RT_DEV Node<R> trace_node(const SceneDev<R> &S, V3<R> ro, V3<R> rd, uint32_t remaining)
+template <typename R, uint32_t SF, bool PRIMARY = false>
+RT_DEV Node<R> trace_node(const SceneDev<R> &S, const PrimScene<R> *P, V3<R> ro, V3<R> rd, uint32_t remaining)
 {
     constexpr bool TRACK = (SF & SF_TRANSPARENT) != 0;
     Node<R> nd;
     nd.has_reflect = nd.has_refract = false;
     nd.lighting = { R(0), R(0), R(0) };
-    Hit<R> h = closest_hit<R, TRACK>(S, ro, rd);
-    nd.hit = h.obj != 0xffffffffu;
+    Hit<R> h;
+    if constexpr (PRIMARY) h = closest_hit_primary<R, TRACK>(S, *P, rd);
+    else h = closest_hit<R, TRACK>(S, ro, rd);
+    nd.hit = h.slot != kNone;
     nd.obj = h.obj;
     nd.t = h.t;
     if (!nd.hit) return nd;
 
-    const HotRec<R> &hot = S.hot[h.obj];
     const ColdRec<R> &cold = S.cold[h.obj];
 
     // prepare_computations, world.rs:242-251; Ray::position, rays.rs:24-28
     V3<R> pt = { ro.x + rd.x * h.t, ro.y + rd.y * h.t, ro.z + rd.z * h.t };
     V3<R> eyev = { -rd.x, -rd.y, -rd.z };
     // Object::normal_at, objects.rs:172-183
-    V3<R> lp = xform_point(hot.inv, pt);
-    V3<R> ln = local_normal(hot.type, hot.ymin, hot.ymax, lp);
+    V3<R> lp = xform_point(cold.inv, pt);
+    V3<R> ln = local_normal(cold.type, cold.ymin, cold.ymax, lp);
     V3<R> wn = { (cold.inv_t[0] * ln.x + cold.inv_t[1] * ln.y) + cold.inv_t[2] * ln.z,
                  (cold.inv_t[3] * ln.x + cold.inv_t[4] * ln.y) + cold.inv_t[5] * ln.z,
                  (cold.inv_t[6] * ln.x + cold.inv_t[7] * ln.y) + cold.inv_t[8] * ln.z };
@@ -420,24 +593,28 @@ RT_DEV Node<R> trace_node(const SceneDev<R> &S, V3<R> ro, V3<R> rd, uint32_t rem
 
     R n1 = R(1), n2 = R(1);
     if constexpr (TRACK) {
-        if (h.top1 != 0xffffffffu) n1 = S.cold[h.top1].refractive_index;
+        if (h.top1 != kNone) n1 = S.cold[S.slot_obj[h.top1]].refractive_index;
         if (!h.hit_open) n2 = cold.refractive_index;
-        else if (h.top1 != h.obj) n2 = S.cold[h.top1].refractive_index;
-        else if (h.top2 != 0xffffffffu) n2 = S.cold[h.top2].refractive_index;
+        else if (h.top1 != h.slot) n2 = S.cold[S.slot_obj[h.top1]].refractive_index;
+        else if (h.top2 != kNone) n2 = S.cold[S.slot_obj[h.top2]].refractive_index;
     }
 
     nd.point = pt; nd.normalv = normalv; nd.over_point = over; nd.under_point = under; nd.reflectv = reflectv;
     nd.inside = inside; nd.n1 = n1; nd.n2 = n2;
 
-    // shade_hit, world.rs:121-123
-    bool shadowed = is_shadowed<R, SF>(S, over);
+    // shade_hit, world.rs:121-123.  is_shadowed (world.rs:146-150) and lighting (lights.rs:49)
+    // both normalise light.position - over_point; the vector is formed once here.
+    V3<R> lvec = { S.light_pos[0] - over.x, S.light_pos[1] - over.y, S.light_pos[2] - over.z };
+    R ldist = Num<R>::sqrt_((lvec.x * lvec.x + lvec.y * lvec.y) + lvec.z * lvec.z);
+    V3<R> lightv = { Num<R>::div(lvec.x, ldist), Num<R>::div(lvec.y, ldist), Num<R>::div(lvec.z, ldist) };
+    bool shadowed = is_shadowed<R, SF>(S, over, lightv, ldist);
     nd.shadowed = shadowed;
 
     // lighting, lights.rs:43-78, evaluated at over_point
     V3<R> clr = { cold.color[0], cold.color[1], cold.color[2] };
     if constexpr ((SF & SF_PATTERN) != 0) {
         if (cold.pattern_type != PT_SOLID) {  // Object::pattern_at_object, objects.rs:200-207
-            V3<R> op = xform_point(hot.inv, over);
+            V3<R> op = xform_point(cold.inv, over);
             V3<R> pp = xform_point(cold.pinv, op);
             clr = pattern_at<R>(cold.pattern_type, { cold.c1[0], cold.c1[1], cold.c1[2] },
                                 { cold.c2[0], cold.c2[1], cold.c2[2] }, pp);
@@ -445,7 +622,6 @@ RT_DEV Node<R> trace_node(const SceneDev<R> &S, V3<R> ro, V3<R> rd, uint32_t rem
     }
     V3<R> li = { S.light_int[0], S.light_int[1], S.light_int[2] };
     V3<R> eff = { clr.x * li.x, clr.y * li.y, clr.z * li.z };
-    V3<R> lightv = normalize3<R>({ S.light_pos[0] - over.x, S.light_pos[1] - over.y, S.light_pos[2] - over.z });
     V3<R> result = { eff.x * cold.ambient, eff.y * cold.ambient, eff.z * cold.ambient };
     if (!shadowed) {
         V3<R> diffuse = { R(0), R(0), R(0) }, specular = { R(0), R(0), R(0) };

@@ -58,63 +58,98 @@ RT_DEV void queue_push(const QueueDev<R> &q, bool active, V3<R> o, V3<R> d, R we
     }
 }
 
-// Flush the per-lane counters: one atomic per wave and counter, spread over shards.
+// Flush the per-lane counters: summed over the wave, then over the workgroup in LDS, then one
+// atomic per workgroup and counter, spread over shards.  Every thread of the block must call it.
 RT_DEV void stats_flush(StatShard *stats, uint32_t level, uint32_t hits, uint32_t overflow)
 {
-    // wave totals via ballot-free butterfly on 32-bit values
+    __shared__ uint32_t s_hits, s_overflow;
+    if (threadIdx.x == 0) { s_hits = 0; s_overflow = 0; }
+    __syncthreads();
     for (int off = 32; off > 0; off >>= 1) {
         hits += __shfl_xor(hits, off);
         overflow |= __shfl_xor(overflow, off);
     }
     if (lane_id() == 0) {
+        if (hits) atomicAdd(&s_hits, hits);
+        if (overflow) atomicOr(&s_overflow, 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
         StatShard *s = stats + (blockIdx.x % kStatShards);
-        if (hits) atomicAdd(&s->hits[level], (unsigned long long)hits);
-        if (overflow) atomicAdd(&s->overflow, 1ull);
+        if (s_hits) atomicAdd(&s->hits[level], (unsigned long long)s_hits);
+        if (s_overflow) atomicAdd(&s->overflow, 1ull);
     }
 }
 
-template <typename R, uint32_t SF>
-__global__ void __launch_bounds__(kBlock)
-k_primary(CameraDev<R> cam, SceneDev<R> S, const double *__restrict__ rays, uint32_t pix_begin, uint32_t n_pix,
-          uint32_t remaining, R *__restrict__ fb, QueueDev<R> out_q, StatShard *__restrict__ stats)
+// The work of one primary ray: trace, store the pixel's own lighting term, queue the children.
+template <typename R, uint32_t SF, bool CAM>
+RT_DEV void primary_ray(const CameraDev<R> &cam, const SceneDev<R> &S, const PrimScene<R> &P,
+                        const double *__restrict__ rays, uint32_t pix_begin, uint32_t k, bool valid, uint32_t remaining,
+                        R *__restrict__ fb, const QueueDev<R> &out_q, uint32_t &hits, uint32_t &overflow)
 {
-    const uint32_t stride = gridDim.x * kBlock;
-    uint32_t hits = 0, overflow = 0;
-    for (uint32_t base = blockIdx.x * kBlock; base < n_pix; base += stride) {
-        const uint32_t k = base + threadIdx.x;
-        const bool valid = k < n_pix;
-        Node<R> nd;
-        nd.hit = false;
-        nd.has_reflect = nd.has_refract = false;
-        nd.lighting = { R(0), R(0), R(0) };
-        if (valid) {
-            V3<R> ro, rd;
-            if (rays) {
-                const double *r = rays + (size_t)k * 6;
-                ro = { R(r[0]), R(r[1]), R(r[2]) };
-                rd = { R(r[3]), R(r[4]), R(r[5]) };
-            } else {
-                const uint32_t p = pix_begin + k;
-                const uint32_t W = cam.hsize;
-                uint32_t y = (uint32_t)((double)p * cam.inv_hsize);
-                int32_t x = (int32_t)(p - y * W);
-                if (x < 0) { y -= 1; x += (int32_t)W; }
-                else if ((uint32_t)x >= W) { y += 1; x -= (int32_t)W; }
-                ray_for_pixel(cam, (uint32_t)x, y, ro, rd);
-            }
-            nd = trace_node<R, SF>(S, ro, rd, remaining);
-            R *px = fb + (size_t)k * 3;
-            px[0] = nd.lighting.x;
-            px[1] = nd.lighting.y;
-            px[2] = nd.lighting.z;
-            hits += nd.hit ? 1u : 0u;
+    Node<R> nd;
+    nd.hit = false;
+    nd.has_reflect = nd.has_refract = false;
+    nd.lighting = { R(0), R(0), R(0) };
+    if (valid) {
+        V3<R> ro, rd;
+        if constexpr (CAM) {
+            const uint32_t p = pix_begin + k;
+            const uint32_t W = cam.hsize;
+            uint32_t y = (uint32_t)((double)p * cam.inv_hsize);
+            int32_t x = (int32_t)(p - y * W);
+            if (x < 0) { y -= 1; x += (int32_t)W; }
+            else if ((uint32_t)x >= W) { y += 1; x -= (int32_t)W; }
+            ray_for_pixel(cam, (uint32_t)x, y, ro, rd);
+            nd = trace_node<R, SF, true>(S, &P, ro, rd, remaining);
+        } else {
+            const double *r = rays + (size_t)k * 6;
+            ro = { R(r[0]), R(r[1]), R(r[2]) };
+            rd = { R(r[3]), R(r[4]), R(r[5]) };
+            nd = trace_node<R, SF, false>(S, nullptr, ro, rd, remaining);
         }
-        if constexpr ((SF & SF_REFLECTIVE) != 0)
-            queue_push(out_q, valid && nd.has_reflect, nd.over_point, nd.reflectv, nd.reflect_factor, k, overflow);
-        if constexpr ((SF & SF_TRANSPARENT) != 0)
-            queue_push(out_q, valid && nd.has_refract, nd.under_point, nd.refract_dir, nd.refract_factor, k, overflow);
+        R *px = fb + (size_t)k * 3;
+        px[0] = nd.lighting.x;
+        px[1] = nd.lighting.y;
+        px[2] = nd.lighting.z;
+        hits += nd.hit ? 1u : 0u;
+    }
+    if constexpr ((SF & SF_REFLECTIVE) != 0)
+        queue_push(out_q, valid && nd.has_reflect, nd.over_point, nd.reflectv, nd.reflect_factor, k, overflow);
+    if constexpr ((SF & SF_TRANSPARENT) != 0)
+        queue_push(out_q, valid && nd.has_refract, nd.under_point, nd.refract_dir, nd.refract_factor, k, overflow);
+}
+
+// CAM = true: the rays are the camera's primary rays of pixels [pix_begin, pix_begin + n_pix),
+// one pixel per thread (no loop: the camera block is dead once the ray exists, which keeps
+// the scalar register file for the object tables), and the intersection walk reads the
+// per-frame primary tables.  CAM = false: the rays come from a caller-supplied array
+// (World::color_at batches), walked with a grid-stride loop.
+template <typename R, uint32_t SF, bool CAM>
+__global__ void __launch_bounds__(kBlock)
+k_primary(CameraDev<R> cam, SceneDev<R> S, PrimScene<R> P, const double *__restrict__ rays, uint32_t pix_begin,
+          uint32_t n_pix, uint32_t remaining, R *__restrict__ fb, QueueDev<R> out_q, StatShard *__restrict__ stats)
+{
+    uint32_t hits = 0, overflow = 0;
+    if constexpr (CAM) {
+        const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+        primary_ray<R, SF, true>(cam, S, P, rays, pix_begin, k, k < n_pix, remaining, fb, out_q, hits, overflow);
+    } else {
+        const uint32_t stride = gridDim.x * kBlock;
+        for (uint32_t base = blockIdx.x * kBlock; base < n_pix; base += stride) {
+            const uint32_t k = base + threadIdx.x;
+            primary_ray<R, SF, false>(cam, S, P, rays, pix_begin, k, k < n_pix, remaining, fb, out_q, hits, overflow);
+        }
     }
     stats_flush(stats, 0, hits, overflow);
+}
+
+// One thread per object: the primary-ray table entry of its slot (see PrimRec).
+template <typename R>
+__global__ void __launch_bounds__(kBlock) k_primary_tables(CameraDev<R> cam, SceneDev<R> S, PrimScene<R> P)
+{
+    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+    if (slot < S.n) make_primary_record<R>(S, P, { cam.origin[0], cam.origin[1], cam.origin[2] }, slot);
 }
 
 template <typename R> RT_DEV void fb_add(R *p, R v);
@@ -146,7 +181,7 @@ k_bounce(SceneDev<R> S, QueueDev<R> in_q, QueueDev<R> out_q, uint32_t remaining,
             V3<R> rd = { b.y, c.x, c.y };
             weight = e.x;
             pixel = pixel_bits_load<R>(e.y);
-            nd = trace_node<R, SF>(S, ro, rd, remaining);
+            nd = trace_node<R, SF, false>(S, nullptr, ro, rd, remaining);
             if (nd.hit) {
                 R *px = fb + (size_t)pixel * 3;
                 fb_add<R>(px + 0, nd.lighting.x * weight);
@@ -215,14 +250,28 @@ __global__ void __launch_bounds__(kBlock) k_quantize(const R *__restrict__ rgb, 
 
 template <typename R>
 hipError_t Launch<R>::primary(uint32_t sf, uint32_t grid, hipStream_t stream, const CameraDev<R> &cam,
-                              const SceneDev<R> &scene, const double *rays, uint32_t pix_begin, uint32_t n_pix,
-                              uint32_t remaining, R *fb, const QueueDev<R> &out_q, StatShard *stats)
+                              const SceneDev<R> &scene, const PrimScene<R> &prim, const double *rays, uint32_t pix_begin,
+                              uint32_t n_pix, uint32_t remaining, R *fb, const QueueDev<R> &out_q, StatShard *stats)
 {
-#define RTX_CALL(SFV)                                                                                          \
-    hipLaunchKernelGGL((k_primary<R, SFV | SF_PATTERN>), dim3(grid), dim3(kBlock), 0, stream, cam, scene, rays, \
-                       pix_begin, n_pix, remaining, fb, out_q, stats)
+#define RTX_CALL(SFV)                                                                                               \
+    if (rays)                                                                                                       \
+        hipLaunchKernelGGL((k_primary<R, SFV | SF_PATTERN, false>), dim3(grid), dim3(kBlock), 0, stream, cam, scene, \
+                           prim, rays, pix_begin, n_pix, remaining, fb, out_q, stats);                              \
+    else                                                                                                            \
+        hipLaunchKernelGGL((k_primary<R, SFV | SF_PATTERN, true>), dim3((n_pix + kBlock - 1) / kBlock), dim3(kBlock), \
+                           0, stream, cam, scene, prim, rays, pix_begin, n_pix, remaining, fb, out_q, stats)
     RTX_SF_SWITCH(sf, RTX_CALL)
 #undef RTX_CALL
+    return hipGetLastError();
+}
+
+template <typename R>
+hipError_t Launch<R>::primary_tables(hipStream_t stream, const CameraDev<R> &cam, const SceneDev<R> &scene,
+                                     const PrimScene<R> &prim)
+{
+    if (scene.n == 0) return hipSuccess;
+    hipLaunchKernelGGL((k_primary_tables<R>), dim3((scene.n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, cam, scene,
+                       prim);
     return hipGetLastError();
 }
 

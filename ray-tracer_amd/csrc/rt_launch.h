@@ -19,8 +19,12 @@ struct Launch {
     // Primary rays of pixels [pix_begin, pix_begin + n_pix) (or rays[0..n_pix) when rays is
     // non-null): intersect, shade, store the lighting term at fb[3*k], queue the children.
     static hipError_t primary(uint32_t sf, uint32_t grid, hipStream_t stream, const CameraDev<R> &cam,
-                              const SceneDev<R> &scene, const double *rays, uint32_t pix_begin, uint32_t n_pix,
-                              uint32_t remaining, R *fb, const QueueDev<R> &out_q, StatShard *stats);
+                              const SceneDev<R> &scene, const PrimScene<R> &prim, const double *rays, uint32_t pix_begin,
+                              uint32_t n_pix, uint32_t remaining, R *fb, const QueueDev<R> &out_q, StatShard *stats);
+    // Fill the per-frame primary-ray tables `prim` (device memory sized by the caller) from
+    // the scene tables and the camera origin.
+    static hipError_t primary_tables(hipStream_t stream, const CameraDev<R> &cam, const SceneDev<R> &scene,
+                                     const PrimScene<R> &prim);
     // One recursion level below the primary rays: consume in_q, add weight * lighting into
     // fb, queue the next level.
     static hipError_t bounce(uint32_t sf, uint32_t grid, hipStream_t stream, const SceneDev<R> &scene,

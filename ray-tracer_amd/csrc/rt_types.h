@@ -1,12 +1,11 @@
 // rt_types.h -- plain data shared by the host-side C ABI and the device code:
-// the repacked object table, the camera block, the secondary-ray queue and the counters.
+// the repacked object tables, the camera block, the secondary-ray queue and the counters.
 #pragma once
 
 #include <stdint.h>
 
 namespace rtx {
 
-// ---- object table -------------------------------------------------------------------
 // Shape tags: src/shapes/objects.rs:14-20.  Pattern tags: src/surfaces/patterns.rs:13-20.
 enum : uint32_t { SH_SPHERE = 0, SH_PLANE = 1, SH_CUBE = 2, SH_CYLINDER = 3, SH_CONE = 4 };
 enum : uint32_t { PT_SOLID = 0, PT_STRIPE = 1, PT_GRADIENT = 2, PT_RING = 3, PT_CHECKER = 4, PT_TEST = 5 };
@@ -21,33 +20,105 @@ enum : uint32_t {
     SF_PATTERN = 8u,      // some object carries a non-solid pattern
 };
 
-// "Hot" record: everything a ray-object test reads.  The object loop indexes it with a
-// wave-uniform index, so it is fetched through the scalar cache into SGPRs.
+// ---- intersection tables -------------------------------------------------------------
+// Objects are regrouped by shape so that each shape gets its own loop with no per-object
+// dispatch.  Within a shape the World's order is kept; a "slot" is an object's position in the
+// concatenation spheres | planes | cubes | cylinders | cones.  Every loop indexes its table
+// with a wave-uniform index, so the records travel through the scalar cache into SGPRs.
+
+// sphere, cube: rows 0..2 of Object.inverse_transform (src/shapes/objects.rs:7)
 template <typename R>
-struct alignas(sizeof(R) * 16) HotRec {
-    R inv[12];  // rows 0..2 of Object.inverse_transform (objects.rs:7)
-    R ymin, ymax;
-    uint32_t type;
-    uint32_t flags;
+struct alignas(sizeof(R) * 4) XformRec {
+    R m[12];
 };
-// "Cold" record: read once per shaded hit, gathered per lane.
+// plane: only row 1 of the inverse is ever read (src/shapes/planes.rs:11-17)
+template <typename R>
+struct alignas(sizeof(R) * 4) PlaneRec {
+    R m[4];
+};
+// cylinder, cone: inverse rows plus the Shape payload (src/shapes/objects.rs:18-19)
+template <typename R>
+struct alignas(sizeof(R) * 4) CappedRec {
+    R m[12];
+    R ymin, ymax;
+    uint32_t closed;
+    uint32_t pad[(2 * sizeof(R) - 4) / 4];
+};
+
+// ---- primary-ray tables -----------------------------------------------------------------
+// Every primary ray starts at the camera, so each object's object-space ray origin and the
+// terms of its intersection test that depend on the origin alone are the same for all pixels.
+// They are evaluated once per frame and object, with the expressions the generic path uses,
+// into these tables (same slot order as the intersection tables).
+template <typename R>
+struct alignas(sizeof(R) * 2) PrimSphereRec {
+    R m[9];    // upper-left 3x3 of Object.inverse_transform (what a direction is multiplied by)
+    R o[3];    // object-space origin
+    R c;       // o.o - 1
+    R pad;
+};
+template <typename R>
+struct alignas(sizeof(R) * 2) PrimPlaneRec {
+    R m[3];    // row 1, columns 0..2 of the inverse
+    R neg_oy;  // -(object-space origin).y
+};
+template <typename R>
+struct alignas(sizeof(R) * 2) PrimCubeRec {
+    R m[9];
+    R lo[3];   // -1 - origin (the tmin numerators of cubes.rs:32)
+    R hi[3];   //  1 - origin (the tmax numerators of cubes.rs:33)
+    R pad;
+};
+template <typename R>
+struct alignas(sizeof(R) * 2) PrimCappedRec {
+    R m[9];
+    R o[3];
+    R o2[3];   // 2 * origin
+    R c;       // cylinder: ox^2 + oz^2 - 1; cone: ox^2 - oy^2 + oz^2
+    R ymin, ymax;
+    uint32_t closed;
+    uint32_t pad[(2 * sizeof(R) - 4) / 4];
+};
+template <typename R>
+struct PrimScene {
+    const PrimSphereRec<R> *sph;
+    const PrimPlaneRec<R> *pln;
+    const PrimCubeRec<R> *cub;
+    const PrimCappedRec<R> *cyl;
+    const PrimCappedRec<R> *con;
+    uint32_t n_sph, n_pln, n_cub, n_cyl, n_con;
+    uint32_t pad;
+};
+
+// Shading record: read once per shaded hit, gathered per lane by original object index.
 template <typename R>
 struct alignas(16) ColdRec {
+    R inv[12];   // rows 0..2 of Object.inverse_transform
     R inv_t[9];  // rows 0..2, cols 0..2 of Object.inverse_transform_transposed (objects.rs:8)
+    R ymin, ymax;
     R color[3];
     R ambient, diffuse, specular, shininess, reflective, transparency, refractive_index;
     R pinv[12];  // rows 0..2 of Pattern.inverse_transform (patterns.rs:7)
     R c1[3], c2[3];
+    uint32_t type;
+    uint32_t flags;
     uint32_t pattern_type;
     uint32_t pad;
 };
 
 template <typename R>
 struct SceneDev {
-    const HotRec<R> *hot;
-    const ColdRec<R> *cold;
+    const XformRec<R> *sph;
+    const PlaneRec<R> *pln;
+    const XformRec<R> *cub;
+    const CappedRec<R> *cyl;
+    const CappedRec<R> *con;
+    const uint32_t *slot_obj;  // slot -> index in World.objects (the tie-break order among equal t)
+    const ColdRec<R> *cold;    // by index in World.objects
+    uint32_t n_sph, n_pln, n_cub, n_cyl, n_con;
     uint32_t n;
     uint32_t flags;
+    uint32_t pad;
     R light_pos[3];
     R light_int[3];
 };

@@ -58,6 +58,8 @@ struct Slot {
     size_t fb_bytes = 0;
     void *aux = nullptr;        // ray upload / probe output
     size_t aux_bytes = 0;
+    void *prim = nullptr;       // per-frame primary-ray tables
+    size_t prim_bytes = 0;
     uint32_t *counts = nullptr; // queue counters, kMaxLevels + 1 per chunk
     size_t counts_n = 0;
     StatShard *shards = nullptr;
@@ -83,7 +85,7 @@ struct rtx_scene {
     rtx_context *ctx = nullptr;
     uint32_t n = 0;
     uint32_t sf = 0;
-    void *d_hot64 = nullptr, *d_cold64 = nullptr, *d_hot32 = nullptr, *d_cold32 = nullptr;
+    void *blob64 = nullptr, *blob32 = nullptr;  // device tables, one allocation per precision
     SceneDev<double> dev64;
     SceneDev<float> dev32;
 };
@@ -149,29 +151,32 @@ int grow(void **ptr, size_t *have, size_t need)
     return RTX_OK;
 }
 
+// Host image of the device tables of one scene in one precision.
 template <typename R>
-void fill_records(const rtx_scene_desc *d, const std::vector<uint8_t> &container, std::vector<HotRec<R>> &hot,
-                  std::vector<ColdRec<R>> &cold)
+struct Tables {
+    std::vector<XformRec<R>> sph, cub;
+    std::vector<PlaneRec<R>> pln;
+    std::vector<CappedRec<R>> cyl, con;
+    std::vector<uint32_t> slot_obj;
+    std::vector<ColdRec<R>> cold;
+};
+
+template <typename R>
+void fill_tables(const rtx_scene_desc *d, const std::vector<uint8_t> &container, Tables<R> &t)
 {
     const uint32_t n = d->n_objects;
-    hot.resize(n);
-    cold.resize(n);
+    t.cold.resize(n);
     for (uint32_t i = 0; i < n; ++i) {
-        HotRec<R> &h = hot[i];
-        ColdRec<R> &c = cold[i];
-        std::memset(&h, 0, sizeof h);
+        ColdRec<R> &c = t.cold[i];
         std::memset(&c, 0, sizeof c);
         const double *inv = d->inverse + (size_t)i * 16;
         const double *invt = d->inverse_transposed + (size_t)i * 16;
         const double *pinv = d->pattern_inverse + (size_t)i * 16;
-        for (int k = 0; k < 12; ++k) h.inv[k] = (R)inv[k];
-        h.ymin = (R)d->ymin[i];
-        h.ymax = (R)d->ymax[i];
-        h.type = d->shape_type[i];
-        h.flags = (d->closed[i] ? OF_CLOSED : 0u) | (d->casts_shadow[i] ? OF_CASTS_SHADOW : 0u) |
-                  (container[i] ? OF_CONTAINER : 0u);
+        for (int k = 0; k < 12; ++k) c.inv[k] = (R)inv[k];
         for (int r = 0; r < 3; ++r)
             for (int k = 0; k < 3; ++k) c.inv_t[r * 3 + k] = (R)invt[r * 4 + k];
+        c.ymin = (R)d->ymin[i];
+        c.ymax = (R)d->ymax[i];
         for (int k = 0; k < 3; ++k) {
             c.color[k] = (R)d->color[(size_t)i * 3 + k];
             c.c1[k] = (R)d->pattern_color1[(size_t)i * 3 + k];
@@ -185,8 +190,86 @@ void fill_records(const rtx_scene_desc *d, const std::vector<uint8_t> &container
         c.transparency = (R)d->transparency[i];
         c.refractive_index = (R)d->refractive_index[i];
         for (int k = 0; k < 12; ++k) c.pinv[k] = (R)pinv[k];
+        c.type = d->shape_type[i];
+        c.flags = (d->closed[i] ? OF_CLOSED : 0u) | (d->casts_shadow[i] ? OF_CASTS_SHADOW : 0u) |
+                  (container[i] ? OF_CONTAINER : 0u);
         c.pattern_type = d->pattern_type[i];
     }
+    // intersection tables: one per shape, World order kept inside each
+    for (uint32_t shape = RTX_SPHERE; shape <= RTX_CONE; ++shape)
+        for (uint32_t i = 0; i < n; ++i) {
+            if (d->shape_type[i] != shape) continue;
+            const double *inv = d->inverse + (size_t)i * 16;
+            t.slot_obj.push_back(i);
+            if (shape == RTX_SPHERE || shape == RTX_CUBE) {
+                XformRec<R> r;
+                for (int k = 0; k < 12; ++k) r.m[k] = (R)inv[k];
+                (shape == RTX_SPHERE ? t.sph : t.cub).push_back(r);
+            } else if (shape == RTX_PLANE) {
+                PlaneRec<R> r;
+                for (int k = 0; k < 4; ++k) r.m[k] = (R)inv[4 + k];
+                t.pln.push_back(r);
+            } else {
+                CappedRec<R> r;
+                std::memset(&r, 0, sizeof r);
+                for (int k = 0; k < 12; ++k) r.m[k] = (R)inv[k];
+                r.ymin = (R)d->ymin[i];
+                r.ymax = (R)d->ymax[i];
+                r.closed = d->closed[i] ? 1u : 0u;
+                (shape == RTX_CYLINDER ? t.cyl : t.con).push_back(r);
+            }
+        }
+}
+
+// One device allocation per scene and precision holding all tables back to back.
+template <typename R>
+int upload_tables(const Tables<R> &t, uint32_t sf, const rtx_scene_desc *d, void **blob, SceneDev<R> *dev)
+{
+    auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t b_sph = pad(t.sph.size() * sizeof(XformRec<R>)), b_pln = pad(t.pln.size() * sizeof(PlaneRec<R>)),
+                 b_cub = pad(t.cub.size() * sizeof(XformRec<R>)), b_cyl = pad(t.cyl.size() * sizeof(CappedRec<R>)),
+                 b_con = pad(t.con.size() * sizeof(CappedRec<R>)), b_slot = pad(t.slot_obj.size() * sizeof(uint32_t)),
+                 b_cold = pad(t.cold.size() * sizeof(ColdRec<R>));
+    const size_t total = b_sph + b_pln + b_cub + b_cyl + b_con + b_slot + b_cold + 256;
+    std::vector<char> host(total, 0);
+    size_t off = 0;
+    auto put = [&](const void *src, size_t bytes, size_t padded) {
+        if (bytes) std::memcpy(host.data() + off, src, bytes);
+        const size_t at = off;
+        off += padded;
+        return at;
+    };
+    const size_t o_sph = put(t.sph.data(), t.sph.size() * sizeof(XformRec<R>), b_sph);
+    const size_t o_pln = put(t.pln.data(), t.pln.size() * sizeof(PlaneRec<R>), b_pln);
+    const size_t o_cub = put(t.cub.data(), t.cub.size() * sizeof(XformRec<R>), b_cub);
+    const size_t o_cyl = put(t.cyl.data(), t.cyl.size() * sizeof(CappedRec<R>), b_cyl);
+    const size_t o_con = put(t.con.data(), t.con.size() * sizeof(CappedRec<R>), b_con);
+    const size_t o_slot = put(t.slot_obj.data(), t.slot_obj.size() * sizeof(uint32_t), b_slot);
+    const size_t o_cold = put(t.cold.data(), t.cold.size() * sizeof(ColdRec<R>), b_cold);
+    HIP_TRY(hipMalloc(blob, total));
+    HIP_TRY(hipMemcpy(*blob, host.data(), total, hipMemcpyHostToDevice));
+    char *base = (char *)*blob;
+    std::memset(dev, 0, sizeof *dev);
+    dev->sph = (const XformRec<R> *)(base + o_sph);
+    dev->pln = (const PlaneRec<R> *)(base + o_pln);
+    dev->cub = (const XformRec<R> *)(base + o_cub);
+    dev->cyl = (const CappedRec<R> *)(base + o_cyl);
+    dev->con = (const CappedRec<R> *)(base + o_con);
+    dev->slot_obj = (const uint32_t *)(base + o_slot);
+    dev->cold = (const ColdRec<R> *)(base + o_cold);
+    dev->n_sph = (uint32_t)t.sph.size();
+    dev->n_pln = (uint32_t)t.pln.size();
+    dev->n_cub = (uint32_t)t.cub.size();
+    dev->n_cyl = (uint32_t)t.cyl.size();
+    dev->n_con = (uint32_t)t.con.size();
+    dev->n = d->n_objects;
+    dev->flags = sf;
+    if (d->n_lights > 0 && d->light_position && d->light_intensity)
+        for (int k = 0; k < 3; ++k) {
+            dev->light_pos[k] = (R)d->light_position[k];
+            dev->light_int[k] = (R)d->light_intensity[k];
+        }
+    return RTX_OK;
 }
 
 template <typename R>
@@ -289,8 +372,30 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Slot *slot, hipStrea
         HIP_TRY(hipMalloc((void **)&slot->counts, counts_need * sizeof(uint32_t)));
         slot->counts_n = counts_need;
     }
+    if (timed) HIP_TRY(hipEventRecord(slot->ev[0], stream));
     HIP_TRY(hipMemsetAsync(slot->counts, 0, counts_need * sizeof(uint32_t), stream));
     HIP_TRY(hipMemsetAsync(slot->shards, 0, sizeof(StatShard) * kStatShards, stream));
+
+    // primary-ray tables: one entry per object, rebuilt every frame from the camera origin
+    PrimScene<R> prim;
+    std::memset(&prim, 0, sizeof prim);
+    const SceneDev<R> &SD = scene_dev<R>(scene);
+    if (cam && SD.n) {
+        auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const size_t b_sph = pad(SD.n_sph * sizeof(PrimSphereRec<R>)), b_pln = pad(SD.n_pln * sizeof(PrimPlaneRec<R>)),
+                     b_cub = pad(SD.n_cub * sizeof(PrimCubeRec<R>)), b_cyl = pad(SD.n_cyl * sizeof(PrimCappedRec<R>)),
+                     b_con = pad(SD.n_con * sizeof(PrimCappedRec<R>));
+        rc = grow(&slot->prim, &slot->prim_bytes, b_sph + b_pln + b_cub + b_cyl + b_con + 256);
+        if (rc) return rc;
+        char *base = (char *)slot->prim;
+        prim.sph = (const PrimSphereRec<R> *)base;
+        prim.pln = (const PrimPlaneRec<R> *)(base + b_sph);
+        prim.cub = (const PrimCubeRec<R> *)(base + b_sph + b_pln);
+        prim.cyl = (const PrimCappedRec<R> *)(base + b_sph + b_pln + b_cub);
+        prim.con = (const PrimCappedRec<R> *)(base + b_sph + b_pln + b_cub + b_cyl);
+        prim.n_sph = SD.n_sph; prim.n_pln = SD.n_pln; prim.n_cub = SD.n_cub; prim.n_cyl = SD.n_cyl; prim.n_con = SD.n_con;
+        HIP_TRY(Launch<R>::primary_tables(stream, *cam, SD, prim));
+    }
 
     R *q_odd = (R *)slot->queues;
     R *q_even = q_odd + cap_odd * 8;
@@ -298,7 +403,6 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Slot *slot, hipStrea
     std::memset(&cam_zero, 0, sizeof cam_zero);
     const SceneDev<R> &S = scene_dev<R>(scene);
     uint32_t launches = 0;
-    if (timed) HIP_TRY(hipEventRecord(slot->ev[0], stream));
     for (uint32_t c = 0; c < n_chunks; ++c) {
         const uint64_t k0 = (uint64_t)c * plan.chunk_pix;
         const uint32_t n = (uint32_t)std::min<uint64_t>(plan.chunk_pix, n_pix - k0);
@@ -314,7 +418,7 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Slot *slot, hipStrea
         };
         R *fb = d_fb + k0 * 3;
         if (timed && c == 0) HIP_TRY(hipEventRecord(slot->ev[2], stream));
-        HIP_TRY(Launch<R>::primary(scene->sf, grid_for(ctx, n), stream, cam ? *cam : cam_zero, S,
+        HIP_TRY(Launch<R>::primary(scene->sf, grid_for(ctx, n), stream, cam ? *cam : cam_zero, S, prim,
                                    d_rays ? d_rays + k0 * 6 : nullptr, (uint32_t)(first_pix + k0), n, max_depth, fb,
                                    queue_at(1), slot->shards));
         if (timed && c == 0) HIP_TRY(hipEventRecord(slot->ev[3], stream));
@@ -515,6 +619,7 @@ void rtx_context_destroy(rtx_context *ctx)
             if (s->queues) (void)hipFree(s->queues);
             if (s->fb) (void)hipFree(s->fb);
             if (s->aux) (void)hipFree(s->aux);
+            if (s->prim) (void)hipFree(s->prim);
             if (s->counts) (void)hipFree(s->counts);
             if (s->shards) (void)hipFree(s->shards);
             if (s->done) (void)hipEventDestroy(s->done);
@@ -588,40 +693,16 @@ int rtx_scene_upload(rtx_context *ctx, const rtx_scene_desc *d, rtx_scene **out)
     s->ctx = ctx;
     s->n = n;
     s->sf = sf;
-    std::vector<HotRec<double>> hot64;
-    std::vector<ColdRec<double>> cold64;
-    std::vector<HotRec<float>> hot32;
-    std::vector<ColdRec<float>> cold32;
-    fill_records<double>(d, container, hot64, cold64);
-    fill_records<float>(d, container, hot32, cold32);
-    auto upload = [&](void **dst, const void *src, size_t bytes) -> int {
-        HIP_TRY(hipMalloc(dst, std::max<size_t>(bytes, 256)));
-        if (bytes) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
-        return RTX_OK;
-    };
-    int rc = upload(&s->d_hot64, hot64.data(), hot64.size() * sizeof(HotRec<double>));
-    if (!rc) rc = upload(&s->d_cold64, cold64.data(), cold64.size() * sizeof(ColdRec<double>));
-    if (!rc) rc = upload(&s->d_hot32, hot32.data(), hot32.size() * sizeof(HotRec<float>));
-    if (!rc) rc = upload(&s->d_cold32, cold32.data(), cold32.size() * sizeof(ColdRec<float>));
+    Tables<double> t64;
+    Tables<float> t32;
+    fill_tables<double>(d, container, t64);
+    fill_tables<float>(d, container, t32);
+    int rc = upload_tables<double>(t64, sf, d, &s->blob64, &s->dev64);
+    if (!rc) rc = upload_tables<float>(t32, sf, d, &s->blob32, &s->dev32);
     if (rc) {
         rtx_scene_destroy(s.release());
         return rc;
     }
-    std::memset(&s->dev64, 0, sizeof s->dev64);
-    std::memset(&s->dev32, 0, sizeof s->dev32);
-    s->dev64.hot = (const HotRec<double> *)s->d_hot64;
-    s->dev64.cold = (const ColdRec<double> *)s->d_cold64;
-    s->dev32.hot = (const HotRec<float> *)s->d_hot32;
-    s->dev32.cold = (const ColdRec<float> *)s->d_cold32;
-    s->dev64.n = s->dev32.n = n;
-    s->dev64.flags = s->dev32.flags = sf;
-    if (d->n_lights > 0 && d->light_position && d->light_intensity)
-        for (int k = 0; k < 3; ++k) {
-            s->dev64.light_pos[k] = d->light_position[k];
-            s->dev64.light_int[k] = d->light_intensity[k];
-            s->dev32.light_pos[k] = (float)d->light_position[k];
-            s->dev32.light_int[k] = (float)d->light_intensity[k];
-        }
     *out = s.release();
     return RTX_OK;
 }
@@ -631,10 +712,8 @@ void rtx_scene_destroy(rtx_scene *s)
     if (!s) return;
     {
         DeviceGuard guard(s->ctx->device);
-        if (s->d_hot64) (void)hipFree(s->d_hot64);
-        if (s->d_cold64) (void)hipFree(s->d_cold64);
-        if (s->d_hot32) (void)hipFree(s->d_hot32);
-        if (s->d_cold32) (void)hipFree(s->d_cold32);
+        if (s->blob64) (void)hipFree(s->blob64);
+        if (s->blob32) (void)hipFree(s->blob32);
     }
     delete s;
 }
