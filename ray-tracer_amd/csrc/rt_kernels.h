@@ -32,7 +32,7 @@ template <> RT_DEV float pixel_bits_store<float>(uint32_t p) { return __uint_as_
 // lanes of the wave that are still in the loop (inactive ones pass active = false).
 template <typename R>
 RT_DEV void queue_push(const QueueDev<R> &q, bool active, V3<R> o, V3<R> d, R weight, uint32_t pixel,
-                       uint32_t &overflow)
+                       StatShard *__restrict__ stats)
 {
     const unsigned long long mask = __ballot(active);
     if (mask == 0ull) return;
@@ -53,103 +53,97 @@ RT_DEV void queue_push(const QueueDev<R> &q, bool active, V3<R> o, V3<R> d, R we
             e.x = weight; e.y = pixel_bits_store<R>(pixel);
             dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = e;
         } else {
-            overflow = 1;
+            atomicAdd(&stats->overflow, 1ull);  // cannot happen: queues are sized for the worst case
         }
     }
 }
 
-// Flush the per-lane counters: summed over the wave, then over the workgroup in LDS, then one
-// atomic per workgroup and counter, spread over shards.  Every thread of the block must call it.
-RT_DEV void stats_flush(StatShard *stats, uint32_t level, uint32_t hits, uint32_t overflow)
+// Count the shaded hits of this wave: one atomic per wave that has any, spread over shards.
+RT_DEV void count_hits(StatShard *__restrict__ stats, uint32_t level, bool hit)
 {
-    __shared__ uint32_t s_hits, s_overflow;
-    if (threadIdx.x == 0) { s_hits = 0; s_overflow = 0; }
-    __syncthreads();
-    for (int off = 32; off > 0; off >>= 1) {
-        hits += __shfl_xor(hits, off);
-        overflow |= __shfl_xor(overflow, off);
-    }
-    if (lane_id() == 0) {
-        if (hits) atomicAdd(&s_hits, hits);
-        if (overflow) atomicOr(&s_overflow, 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        StatShard *s = stats + (blockIdx.x % kStatShards);
-        if (s_hits) atomicAdd(&s->hits[level], (unsigned long long)s_hits);
-        if (s_overflow) atomicAdd(&s->overflow, 1ull);
+    const unsigned long long mask = __ballot(hit);
+    if (mask == 0ull) return;
+    const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+    if (lane_id() == leader) {
+        const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+        atomicAdd(&stats[wave % kStatShards].hits[level], (unsigned long long)__popcll(mask));
     }
 }
 
-// The work of one primary ray: trace, store the pixel's own lighting term, queue the children.
+// The work of one primary ray once it exists: trace, store the pixel's own lighting term,
+// queue the children.
 template <typename R, uint32_t SF, bool CAM>
-RT_DEV void primary_ray(const CameraDev<R> &cam, const SceneDev<R> &S, const PrimScene<R> &P,
-                        const double *__restrict__ rays, uint32_t pix_begin, uint32_t k, bool valid, uint32_t remaining,
-                        R *__restrict__ fb, const QueueDev<R> &out_q, uint32_t &hits, uint32_t &overflow)
+RT_DEV void primary_ray(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> ro, V3<R> rd, uint32_t k, bool valid,
+                        uint32_t remaining, R *__restrict__ fb, const QueueDev<R> &out_q, StatShard *__restrict__ stats)
 {
     Node<R> nd;
     nd.hit = false;
     nd.has_reflect = nd.has_refract = false;
     nd.lighting = { R(0), R(0), R(0) };
     if (valid) {
-        V3<R> ro, rd;
-        if constexpr (CAM) {
-            const uint32_t p = pix_begin + k;
-            const uint32_t W = cam.hsize;
-            uint32_t y = (uint32_t)((double)p * cam.inv_hsize);
-            int32_t x = (int32_t)(p - y * W);
-            if (x < 0) { y -= 1; x += (int32_t)W; }
-            else if ((uint32_t)x >= W) { y += 1; x -= (int32_t)W; }
-            ray_for_pixel(cam, (uint32_t)x, y, ro, rd);
-            nd = trace_node<R, SF, true>(S, &P, ro, rd, remaining);
-        } else {
-            const double *r = rays + (size_t)k * 6;
-            ro = { R(r[0]), R(r[1]), R(r[2]) };
-            rd = { R(r[3]), R(r[4]), R(r[5]) };
-            nd = trace_node<R, SF, false>(S, nullptr, ro, rd, remaining);
-        }
+        nd = trace_node<R, SF, CAM>(S, CAM ? &P : nullptr, ro, rd, remaining);
         R *px = fb + (size_t)k * 3;
         px[0] = nd.lighting.x;
         px[1] = nd.lighting.y;
         px[2] = nd.lighting.z;
-        hits += nd.hit ? 1u : 0u;
     }
+    count_hits(stats, 0, valid && nd.hit);
     if constexpr ((SF & SF_REFLECTIVE) != 0)
-        queue_push(out_q, valid && nd.has_reflect, nd.over_point, nd.reflectv, nd.reflect_factor, k, overflow);
+        queue_push(out_q, valid && nd.has_reflect, nd.over_point, nd.reflectv, nd.reflect_factor, k, stats);
     if constexpr ((SF & SF_TRANSPARENT) != 0)
-        queue_push(out_q, valid && nd.has_refract, nd.under_point, nd.refract_dir, nd.refract_factor, k, overflow);
+        queue_push(out_q, valid && nd.has_refract, nd.under_point, nd.refract_dir, nd.refract_factor, k, stats);
 }
 
-// CAM = true: the rays are the camera's primary rays of pixels [pix_begin, pix_begin + n_pix),
-// one pixel per thread (no loop: the camera block is dead once the ray exists, which keeps
-// the scalar register file for the object tables), and the intersection walk reads the
-// per-frame primary tables.  CAM = false: the rays come from a caller-supplied array
-// (World::color_at batches), walked with a grid-stride loop.
-template <typename R, uint32_t SF, bool CAM>
+// Camera rays of rows [row0, row0 + n_rows): each wave takes one 64-pixel segment of a row,
+// one pixel per lane, so its framebuffer stores cover one contiguous run.  There is no loop:
+// the camera block is dead once the ray exists, which leaves the scalar register file to the
+// object tables.  The intersection walk reads the per-frame primary tables.
+template <typename R, uint32_t SF>
 __global__ void __launch_bounds__(kBlock)
-k_primary(CameraDev<R> cam, SceneDev<R> S, PrimScene<R> P, const double *__restrict__ rays, uint32_t pix_begin,
-          uint32_t n_pix, uint32_t remaining, R *__restrict__ fb, QueueDev<R> out_q, StatShard *__restrict__ stats)
+k_primary_camera(CameraDev<R> cam, SceneDev<R> S, PrimScene<R> P, uint32_t row0, uint32_t n_rows, uint32_t segs_per_row,
+                 uint32_t remaining, R *__restrict__ fb, QueueDev<R> out_q, StatShard *__restrict__ stats)
 {
-    uint32_t hits = 0, overflow = 0;
-    if constexpr (CAM) {
-        const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
-        primary_ray<R, SF, true>(cam, S, P, rays, pix_begin, k, k < n_pix, remaining, fb, out_q, hits, overflow);
-    } else {
-        const uint32_t stride = gridDim.x * kBlock;
-        for (uint32_t base = blockIdx.x * kBlock; base < n_pix; base += stride) {
-            const uint32_t k = base + threadIdx.x;
-            primary_ray<R, SF, false>(cam, S, P, rays, pix_begin, k, k < n_pix, remaining, fb, out_q, hits, overflow);
-        }
-    }
-    stats_flush(stats, 0, hits, overflow);
+    const uint32_t seg = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
+    const uint32_t row = seg / segs_per_row;
+    const uint32_t x = (seg - row * segs_per_row) * 64u + (threadIdx.x & 63u);
+    const bool valid = row < n_rows && x < cam.hsize;
+    V3<R> ro = { R(0), R(0), R(0) }, rd = ro;
+    if (valid) ray_for_pixel(cam, x, row0 + row, ro, rd);
+    primary_ray<R, SF, true>(S, P, ro, rd, row * cam.hsize + x, valid, remaining, fb, out_q, stats);
 }
 
-// One thread per object: the primary-ray table entry of its slot (see PrimRec).
-template <typename R>
-__global__ void __launch_bounds__(kBlock) k_primary_tables(CameraDev<R> cam, SceneDev<R> S, PrimScene<R> P)
+// Rays from a caller-supplied array (World::color_at batches), walked with a grid-stride loop.
+template <typename R, uint32_t SF>
+__global__ void __launch_bounds__(kBlock)
+k_primary_rays(SceneDev<R> S, const double *__restrict__ rays, uint32_t n, uint32_t remaining, R *__restrict__ fb,
+               QueueDev<R> out_q, StatShard *__restrict__ stats)
 {
-    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
-    if (slot < S.n) make_primary_record<R>(S, P, { cam.origin[0], cam.origin[1], cam.origin[2] }, slot);
+    const uint32_t stride = gridDim.x * kBlock;
+    const PrimScene<R> none = {};
+    for (uint32_t base = blockIdx.x * kBlock; base < n; base += stride) {
+        const uint32_t k = base + threadIdx.x;
+        const bool valid = k < n;
+        V3<R> ro = { R(0), R(0), R(0) }, rd = ro;
+        if (valid) {
+            const double *r = rays + (size_t)k * 6;
+            ro = { R(r[0]), R(r[1]), R(r[2]) };
+            rd = { R(r[3]), R(r[4]), R(r[5]) };
+        }
+        primary_ray<R, SF, false>(S, none, ro, rd, k, valid, remaining, fb, out_q, stats);
+    }
+}
+
+// First kernel of a frame: zero the queue counters and the hit counters, and let one thread
+// per object write the primary-ray table entry of its slot (n_tables = 0 for ray batches).
+template <typename R>
+__global__ void __launch_bounds__(kBlock)
+k_frame_begin(CameraDev<R> cam, SceneDev<R> S, PrimScene<R> P, uint32_t n_tables, uint32_t *__restrict__ zero_a,
+              uint32_t n_a, uint32_t *__restrict__ zero_b, uint32_t n_b)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n_a) zero_a[i] = 0u;
+    if (i < n_b) zero_b[i] = 0u;
+    if (i < n_tables) make_primary_record<R>(S, P, { cam.origin[0], cam.origin[1], cam.origin[2] }, i);
 }
 
 template <typename R> RT_DEV void fb_add(R *p, R v);
@@ -164,7 +158,6 @@ k_bounce(SceneDev<R> S, QueueDev<R> in_q, QueueDev<R> out_q, uint32_t remaining,
     uint32_t n = *in_q.count;
     if (n > in_q.capacity) n = in_q.capacity;
     const uint32_t stride = gridDim.x * kBlock;
-    uint32_t hits = 0, overflow = 0;
     for (uint32_t base = blockIdx.x * kBlock; base < n; base += stride) {
         const uint32_t k = base + threadIdx.x;
         const bool valid = k < n;
@@ -187,17 +180,14 @@ k_bounce(SceneDev<R> S, QueueDev<R> in_q, QueueDev<R> out_q, uint32_t remaining,
                 fb_add<R>(px + 0, nd.lighting.x * weight);
                 fb_add<R>(px + 1, nd.lighting.y * weight);
                 fb_add<R>(px + 2, nd.lighting.z * weight);
-                hits += 1u;
             }
         }
+        count_hits(stats, level, valid && nd.hit);
         if constexpr ((SF & SF_REFLECTIVE) != 0)
-            queue_push(out_q, valid && nd.has_reflect, nd.over_point, nd.reflectv, weight * nd.reflect_factor, pixel,
-                       overflow);
+            queue_push(out_q, valid && nd.has_reflect, nd.over_point, nd.reflectv, weight * nd.reflect_factor, pixel, stats);
         if constexpr ((SF & SF_TRANSPARENT) != 0)
-            queue_push(out_q, valid && nd.has_refract, nd.under_point, nd.refract_dir, weight * nd.refract_factor,
-                       pixel, overflow);
+            queue_push(out_q, valid && nd.has_refract, nd.under_point, nd.refract_dir, weight * nd.refract_factor, pixel, stats);
     }
-    stats_flush(stats, level, hits, overflow);
 }
 
 template <typename R>
@@ -249,29 +239,45 @@ __global__ void __launch_bounds__(kBlock) k_quantize(const R *__restrict__ rgb, 
     }
 
 template <typename R>
-hipError_t Launch<R>::primary(uint32_t sf, uint32_t grid, hipStream_t stream, const CameraDev<R> &cam,
-                              const SceneDev<R> &scene, const PrimScene<R> &prim, const double *rays, uint32_t pix_begin,
-                              uint32_t n_pix, uint32_t remaining, R *fb, const QueueDev<R> &out_q, StatShard *stats)
+hipError_t Launch<R>::primary_camera(uint32_t sf, hipStream_t stream, const CameraDev<R> &cam, const SceneDev<R> &scene,
+                                     const PrimScene<R> &prim, uint32_t row0, uint32_t n_rows, uint32_t remaining, R *fb,
+                                     const QueueDev<R> &out_q, StatShard *stats)
 {
+    const uint32_t segs_per_row = (cam.hsize + 63u) / 64u;
+    const uint64_t segs = (uint64_t)segs_per_row * n_rows;
+    const uint32_t grid = (uint32_t)((segs + kBlock / 64 - 1) / (kBlock / 64));
 #define RTX_CALL(SFV)                                                                                               \
-    if (rays)                                                                                                       \
-        hipLaunchKernelGGL((k_primary<R, SFV | SF_PATTERN, false>), dim3(grid), dim3(kBlock), 0, stream, cam, scene, \
-                           prim, rays, pix_begin, n_pix, remaining, fb, out_q, stats);                              \
-    else                                                                                                            \
-        hipLaunchKernelGGL((k_primary<R, SFV | SF_PATTERN, true>), dim3((n_pix + kBlock - 1) / kBlock), dim3(kBlock), \
-                           0, stream, cam, scene, prim, rays, pix_begin, n_pix, remaining, fb, out_q, stats)
+    hipLaunchKernelGGL((k_primary_camera<R, SFV | SF_PATTERN>), dim3(grid), dim3(kBlock), 0, stream, cam, scene, prim, \
+                       row0, n_rows, segs_per_row, remaining, fb, out_q, stats)
     RTX_SF_SWITCH(sf, RTX_CALL)
 #undef RTX_CALL
     return hipGetLastError();
 }
 
 template <typename R>
-hipError_t Launch<R>::primary_tables(hipStream_t stream, const CameraDev<R> &cam, const SceneDev<R> &scene,
-                                     const PrimScene<R> &prim)
+hipError_t Launch<R>::primary_rays(uint32_t sf, uint32_t grid, hipStream_t stream, const SceneDev<R> &scene,
+                                   const double *rays, uint32_t n, uint32_t remaining, R *fb, const QueueDev<R> &out_q,
+                                   StatShard *stats)
 {
-    if (scene.n == 0) return hipSuccess;
-    hipLaunchKernelGGL((k_primary_tables<R>), dim3((scene.n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, cam, scene,
-                       prim);
+#define RTX_CALL(SFV)                                                                                           \
+    hipLaunchKernelGGL((k_primary_rays<R, SFV | SF_PATTERN>), dim3(grid), dim3(kBlock), 0, stream, scene, rays, n, \
+                       remaining, fb, out_q, stats)
+    RTX_SF_SWITCH(sf, RTX_CALL)
+#undef RTX_CALL
+    return hipGetLastError();
+}
+
+template <typename R>
+hipError_t Launch<R>::frame_begin(hipStream_t stream, const CameraDev<R> *cam, const SceneDev<R> &scene,
+                                  const PrimScene<R> &prim, uint32_t *zero_a, uint32_t n_a, uint32_t *zero_b, uint32_t n_b)
+{
+    const uint32_t n_tables = cam ? scene.n : 0u;
+    const uint32_t n = n_tables > n_a ? (n_tables > n_b ? n_tables : n_b) : (n_a > n_b ? n_a : n_b);
+    if (n == 0) return hipSuccess;
+    CameraDev<R> c = {};
+    if (cam) c = *cam;
+    hipLaunchKernelGGL((k_frame_begin<R>), dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, c, scene, prim,
+                       n_tables, zero_a, n_a, zero_b, n_b);
     return hipGetLastError();
 }
 

@@ -16,15 +16,21 @@ constexpr uint32_t kBlock = 256;
 
 template <typename R>
 struct Launch {
-    // Primary rays of pixels [pix_begin, pix_begin + n_pix) (or rays[0..n_pix) when rays is
-    // non-null): intersect, shade, store the lighting term at fb[3*k], queue the children.
-    static hipError_t primary(uint32_t sf, uint32_t grid, hipStream_t stream, const CameraDev<R> &cam,
-                              const SceneDev<R> &scene, const PrimScene<R> &prim, const double *rays, uint32_t pix_begin,
-                              uint32_t n_pix, uint32_t remaining, R *fb, const QueueDev<R> &out_q, StatShard *stats);
-    // Fill the per-frame primary-ray tables `prim` (device memory sized by the caller) from
-    // the scene tables and the camera origin.
-    static hipError_t primary_tables(hipStream_t stream, const CameraDev<R> &cam, const SceneDev<R> &scene,
-                                     const PrimScene<R> &prim);
+    // Camera rays of rows [row0, row0 + n_rows): intersect, shade, store the lighting term at
+    // fb[3 * (row * hsize + x)] (row relative to row0), queue the children.
+    static hipError_t primary_camera(uint32_t sf, hipStream_t stream, const CameraDev<R> &cam, const SceneDev<R> &scene,
+                                     const PrimScene<R> &prim, uint32_t row0, uint32_t n_rows, uint32_t remaining, R *fb,
+                                     const QueueDev<R> &out_q, StatShard *stats);
+    // The same for rays[0..n) supplied by the caller (6 doubles each), result at fb[3 * k].
+    static hipError_t primary_rays(uint32_t sf, uint32_t grid, hipStream_t stream, const SceneDev<R> &scene,
+                                   const double *rays, uint32_t n, uint32_t remaining, R *fb, const QueueDev<R> &out_q,
+                                   StatShard *stats);
+    // First kernel of every frame: clears the two counter arrays and, for camera renders
+    // (cam != nullptr), fills the per-frame primary-ray tables `prim` (device memory sized by
+    // the caller) from the scene tables and the camera origin.
+    static hipError_t frame_begin(hipStream_t stream, const CameraDev<R> *cam, const SceneDev<R> &scene,
+                                  const PrimScene<R> &prim, uint32_t *zero_a, uint32_t n_a, uint32_t *zero_b,
+                                  uint32_t n_b);
     // One recursion level below the primary rays: consume in_q, add weight * lighting into
     // fb, queue the next level.
     static hipError_t bounce(uint32_t sf, uint32_t grid, hipStream_t stream, const SceneDev<R> &scene,

@@ -142,7 +142,7 @@ struct QueueDev {
 };
 
 // Per-level counters, one block of shards per render call (summed on the host).
-constexpr int kStatShards = 64;
+constexpr int kStatShards = 256;
 struct StatShard {
     unsigned long long hits[8];  // shaded hits (= is_shadowed calls) per recursion level
     unsigned long long overflow;

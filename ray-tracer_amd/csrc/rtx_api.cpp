@@ -373,8 +373,6 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Slot *slot, hipStrea
         slot->counts_n = counts_need;
     }
     if (timed) HIP_TRY(hipEventRecord(slot->ev[0], stream));
-    HIP_TRY(hipMemsetAsync(slot->counts, 0, counts_need * sizeof(uint32_t), stream));
-    HIP_TRY(hipMemsetAsync(slot->shards, 0, sizeof(StatShard) * kStatShards, stream));
 
     // primary-ray tables: one entry per object, rebuilt every frame from the camera origin
     PrimScene<R> prim;
@@ -394,13 +392,12 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Slot *slot, hipStrea
         prim.cyl = (const PrimCappedRec<R> *)(base + b_sph + b_pln + b_cub);
         prim.con = (const PrimCappedRec<R> *)(base + b_sph + b_pln + b_cub + b_cyl);
         prim.n_sph = SD.n_sph; prim.n_pln = SD.n_pln; prim.n_cub = SD.n_cub; prim.n_cyl = SD.n_cyl; prim.n_con = SD.n_con;
-        HIP_TRY(Launch<R>::primary_tables(stream, *cam, SD, prim));
     }
+    HIP_TRY(Launch<R>::frame_begin(stream, cam, SD, prim, slot->counts, (uint32_t)counts_need, (uint32_t *)slot->shards,
+                                   (uint32_t)(sizeof(StatShard) * kStatShards / sizeof(uint32_t))));
 
     R *q_odd = (R *)slot->queues;
     R *q_even = q_odd + cap_odd * 8;
-    CameraDev<R> cam_zero;
-    std::memset(&cam_zero, 0, sizeof cam_zero);
     const SceneDev<R> &S = scene_dev<R>(scene);
     uint32_t launches = 0;
     for (uint32_t c = 0; c < n_chunks; ++c) {
@@ -418,9 +415,14 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Slot *slot, hipStrea
         };
         R *fb = d_fb + k0 * 3;
         if (timed && c == 0) HIP_TRY(hipEventRecord(slot->ev[2], stream));
-        HIP_TRY(Launch<R>::primary(scene->sf, grid_for(ctx, n), stream, cam ? *cam : cam_zero, S, prim,
-                                   d_rays ? d_rays + k0 * 6 : nullptr, (uint32_t)(first_pix + k0), n, max_depth, fb,
-                                   queue_at(1), slot->shards));
+        if (cam) {
+            const uint32_t W = cam->hsize;
+            HIP_TRY(Launch<R>::primary_camera(scene->sf, stream, *cam, S, prim, (uint32_t)((first_pix + k0) / W), n / W,
+                                              max_depth, fb, queue_at(1), slot->shards));
+        } else {
+            HIP_TRY(Launch<R>::primary_rays(scene->sf, grid_for(ctx, n), stream, S, d_rays + k0 * 6, n, max_depth, fb,
+                                            queue_at(1), slot->shards));
+        }
         if (timed && c == 0) HIP_TRY(hipEventRecord(slot->ev[3], stream));
         ++launches;
         for (uint32_t L = 1; L <= plan.levels; ++L) {
