@@ -108,8 +108,8 @@ const char *rtx_last_error(void);
 /* One context per GPU.  device_id < 0 selects the current HIP device. */
 int rtx_context_create(int device_id, rtx_context **out);
 void rtx_context_destroy(rtx_context *ctx);
-/* Upper bound in bytes for the secondary-ray queues of one render call (default 8 GiB);
- * frames that could exceed it are rendered in row chunks. */
+/* Upper bound in bytes for the secondary-ray queues of one render call (default: a sixth of
+ * the device memory, at least 8 GiB); frames that could exceed it are rendered in row chunks. */
 int rtx_context_set_workspace_limit(rtx_context *ctx, size_t bytes);
 
 /* Replaces the World a render borrows (src/scenes/world.rs:6-9): validates, repacks and

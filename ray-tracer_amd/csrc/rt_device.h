@@ -208,21 +208,33 @@ template <typename R> RT_DEV R cone_c(V3<R> o) { return (o.x * o.x - o.y * o.y) 
 template <typename R> RT_DEV V3<R> twice(V3<R> o) { return { R(2) * o.x, R(2) * o.y, R(2) * o.z }; }
 
 // ---- walking the object tables ---------------------------------------------------------
-// Visit records 0..n-1 of one table with a wave-uniform index: the records travel through
-// the scalar cache into SGPRs, and the other waves of the SIMD cover the fetch latency.
+// Visit records 0..n-1 of one table with a wave-uniform index.  The table is read through a
+// constant-address-space pointer: that is what makes the compiler fetch each record once per
+// wave through the scalar cache into SGPRs even inside loops that also store to memory (with a
+// generic pointer it falls back to one vector load per lane there).  The tables are written
+// before the launch and never by a kernel that walks them.  The other waves of the SIMD cover
+// the fetch latency.
+#define RT_CONSTANT_AS __attribute__((address_space(4)))
 template <typename Rec, typename Body>
-RT_DEV void walk_table(const Rec *__restrict__ recs, uint32_t n, uint32_t slot0, Body &&body)
+RT_DEV void walk_table(const Rec *recs, uint32_t n, uint32_t slot0, Body &&body)
 {
+    const RT_CONSTANT_AS Rec *table = (const RT_CONSTANT_AS Rec *)recs;
 #if RTX_WALK_PREFETCH
     if (n == 0) return;
-    Rec cur = recs[0];
+    Rec cur;
+    __builtin_memcpy(&cur, table, sizeof(Rec));
     for (uint32_t i = 0; i < n; ++i) {
-        const Rec nxt = recs[(i + 1 < n) ? i + 1 : i];
+        Rec nxt;
+        __builtin_memcpy(&nxt, table + ((i + 1 < n) ? i + 1 : i), sizeof(Rec));
         body(cur, slot0 + i);
         cur = nxt;
     }
 #else
-    for (uint32_t i = 0; i < n; ++i) body(recs[i], slot0 + i);
+    for (uint32_t i = 0; i < n; ++i) {
+        Rec rec;
+        __builtin_memcpy(&rec, table + i, sizeof(Rec));
+        body(rec, slot0 + i);
+    }
 #endif
 }
 

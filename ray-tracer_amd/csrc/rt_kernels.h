@@ -28,10 +28,11 @@ template <typename R> RT_DEV R pixel_bits_store(uint32_t p);
 template <> RT_DEV double pixel_bits_store<double>(uint32_t p) { return __longlong_as_double((long long)p); }
 template <> RT_DEV float pixel_bits_store<float>(uint32_t p) { return __uint_as_float(p); }
 
-// Append (o, d, weight, pixel) for every lane with `active` set.  Must be reached by all
-// lanes of the wave that are still in the loop (inactive ones pass active = false).
+// Append (o, d, weight, pixel) to sub-queue `sub` for every lane with `active` set.  Must be
+// reached by all lanes of the wave (inactive ones pass active = false): the wave reserves its
+// slots with one atomic.
 template <typename R>
-RT_DEV void queue_push(const QueueDev<R> &q, bool active, V3<R> o, V3<R> d, R weight, uint32_t pixel,
+RT_DEV void queue_push(const QueueDev<R> &q, uint32_t sub, bool active, V3<R> o, V3<R> d, R weight, uint32_t pixel,
                        StatShard *__restrict__ stats)
 {
     const unsigned long long mask = __ballot(active);
@@ -39,13 +40,13 @@ RT_DEV void queue_push(const QueueDev<R> &q, bool active, V3<R> o, V3<R> d, R we
     const uint32_t lane = lane_id();
     const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
     uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(q.count, (uint32_t)__popcll(mask));
+    if (lane == leader) base = atomicAdd(q.count + (size_t)sub * kCountStride, (uint32_t)__popcll(mask));
     base = __shfl(base, (int)leader);
     if (active) {
         const uint32_t idx = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        if (idx < q.capacity) {
+        if (idx < q.cap_sub) {
             using V2 = typename Vec2T<R>::type;
-            V2 *dst = reinterpret_cast<V2 *>(q.rec) + (size_t)idx * 4;
+            V2 *dst = reinterpret_cast<V2 *>(q.rec) + ((size_t)sub * q.cap_sub + idx) * 4;
             V2 a, b, c, e;
             a.x = o.x; a.y = o.y;
             b.x = o.z; b.y = d.x;
@@ -59,13 +60,13 @@ RT_DEV void queue_push(const QueueDev<R> &q, bool active, V3<R> o, V3<R> d, R we
 }
 
 // Count the shaded hits of this wave: one atomic per wave that has any, spread over shards.
-RT_DEV void count_hits(StatShard *__restrict__ stats, uint32_t level, bool hit)
+RT_DEV void count_hits(StatShard *__restrict__ stats, uint32_t group, uint32_t level, bool hit)
 {
     const unsigned long long mask = __ballot(hit);
     if (mask == 0ull) return;
     const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
     if (lane_id() == leader) {
-        const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+        const uint32_t wave = group * (kBlock / 64) + (threadIdx.x >> 6);
         atomicAdd(&stats[wave % kStatShards].hits[level], (unsigned long long)__popcll(mask));
     }
 }
@@ -87,11 +88,12 @@ RT_DEV void primary_ray(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> ro, V
         px[1] = nd.lighting.y;
         px[2] = nd.lighting.z;
     }
-    count_hits(stats, 0, valid && nd.hit);
+    count_hits(stats, blockIdx.x, 0, valid && nd.hit);
+    const uint32_t sub = blockIdx.x & out_q.sub_mask;
     if constexpr ((SF & SF_REFLECTIVE) != 0)
-        queue_push(out_q, valid && nd.has_reflect, nd.over_point, nd.reflectv, nd.reflect_factor, k, stats);
+        queue_push(out_q, sub, valid && nd.has_reflect, nd.over_point, nd.reflectv, nd.reflect_factor, k, stats);
     if constexpr ((SF & SF_TRANSPARENT) != 0)
-        queue_push(out_q, valid && nd.has_refract, nd.under_point, nd.refract_dir, nd.refract_factor, k, stats);
+        queue_push(out_q, sub, valid && nd.has_refract, nd.under_point, nd.refract_dir, nd.refract_factor, k, stats);
 }
 
 // Camera rays of rows [row0, row0 + n_rows): each wave takes one 64-pixel segment of a row,
@@ -112,25 +114,22 @@ k_primary_camera(CameraDev<R> cam, SceneDev<R> S, PrimScene<R> P, uint32_t row0,
     primary_ray<R, SF, true>(S, P, ro, rd, row * cam.hsize + x, valid, remaining, fb, out_q, stats);
 }
 
-// Rays from a caller-supplied array (World::color_at batches), walked with a grid-stride loop.
+// Rays from a caller-supplied array (World::color_at batches), one per thread.
 template <typename R, uint32_t SF>
 __global__ void __launch_bounds__(kBlock)
 k_primary_rays(SceneDev<R> S, const double *__restrict__ rays, uint32_t n, uint32_t remaining, R *__restrict__ fb,
                QueueDev<R> out_q, StatShard *__restrict__ stats)
 {
-    const uint32_t stride = gridDim.x * kBlock;
     const PrimScene<R> none = {};
-    for (uint32_t base = blockIdx.x * kBlock; base < n; base += stride) {
-        const uint32_t k = base + threadIdx.x;
-        const bool valid = k < n;
-        V3<R> ro = { R(0), R(0), R(0) }, rd = ro;
-        if (valid) {
-            const double *r = rays + (size_t)k * 6;
-            ro = { R(r[0]), R(r[1]), R(r[2]) };
-            rd = { R(r[3]), R(r[4]), R(r[5]) };
-        }
-        primary_ray<R, SF, false>(S, none, ro, rd, k, valid, remaining, fb, out_q, stats);
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = k < n;
+    V3<R> ro = { R(0), R(0), R(0) }, rd = ro;
+    if (valid) {
+        const double *r = rays + (size_t)k * 6;
+        ro = { R(r[0]), R(r[1]), R(r[2]) };
+        rd = { R(r[3]), R(r[4]), R(r[5]) };
     }
+    primary_ray<R, SF, false>(S, none, ro, rd, k, valid, remaining, fb, out_q, stats);
 }
 
 // First kernel of a frame: zero the queue counters and the hit counters, and let one thread
@@ -150,44 +149,48 @@ template <typename R> RT_DEV void fb_add(R *p, R v);
 template <> RT_DEV void fb_add<double>(double *p, double v) { unsafeAtomicAdd(p, v); }
 template <> RT_DEV void fb_add<float>(float *p, float v) { unsafeAtomicAdd(p, v); }
 
+// One recursion level: one queued ray per thread.  blockIdx.y selects the sub-queue and the
+// grid's x extent covers its worst-case length, so workgroups past the actual length leave at
+// once.  The children go to sub-queue (x + y) mod n_sub: every output sub-queue is fed by
+// exactly gridDim.x workgroups, which is the bound the host sizes cap_sub with.
 template <typename R, uint32_t SF>
 __global__ void __launch_bounds__(kBlock)
 k_bounce(SceneDev<R> S, QueueDev<R> in_q, QueueDev<R> out_q, uint32_t remaining, uint32_t level,
          R *__restrict__ fb, StatShard *__restrict__ stats)
 {
-    uint32_t n = *in_q.count;
-    if (n > in_q.capacity) n = in_q.capacity;
-    const uint32_t stride = gridDim.x * kBlock;
-    for (uint32_t base = blockIdx.x * kBlock; base < n; base += stride) {
-        const uint32_t k = base + threadIdx.x;
-        const bool valid = k < n;
-        Node<R> nd;
-        nd.hit = false;
-        nd.has_reflect = nd.has_refract = false;
-        R weight = R(0);
-        uint32_t pixel = 0;
-        if (valid) {
-            using V2 = typename Vec2T<R>::type;
-            const V2 *src = reinterpret_cast<const V2 *>(in_q.rec) + (size_t)k * 4;
-            const V2 a = src[0], b = src[1], c = src[2], e = src[3];
-            V3<R> ro = { a.x, a.y, b.x };
-            V3<R> rd = { b.y, c.x, c.y };
-            weight = e.x;
-            pixel = pixel_bits_load<R>(e.y);
-            nd = trace_node<R, SF, false>(S, nullptr, ro, rd, remaining);
-            if (nd.hit) {
-                R *px = fb + (size_t)pixel * 3;
-                fb_add<R>(px + 0, nd.lighting.x * weight);
-                fb_add<R>(px + 1, nd.lighting.y * weight);
-                fb_add<R>(px + 2, nd.lighting.z * weight);
-            }
+    const uint32_t sub_in = blockIdx.y;
+    uint32_t n = in_q.count[(size_t)sub_in * kCountStride];
+    if (n > in_q.cap_sub) n = in_q.cap_sub;
+    if (blockIdx.x * kBlock >= n) return;
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = k < n;
+    Node<R> nd;
+    nd.hit = false;
+    nd.has_reflect = nd.has_refract = false;
+    R weight = R(0);
+    uint32_t pixel = 0;
+    if (valid) {
+        using V2 = typename Vec2T<R>::type;
+        const V2 *src = reinterpret_cast<const V2 *>(in_q.rec) + ((size_t)sub_in * in_q.cap_sub + k) * 4;
+        const V2 a = src[0], b = src[1], c = src[2], e = src[3];
+        V3<R> ro = { a.x, a.y, b.x };
+        V3<R> rd = { b.y, c.x, c.y };
+        weight = e.x;
+        pixel = pixel_bits_load<R>(e.y);
+        nd = trace_node<R, SF, false>(S, nullptr, ro, rd, remaining);
+        if (nd.hit) {
+            R *px = fb + (size_t)pixel * 3;
+            fb_add<R>(px + 0, nd.lighting.x * weight);
+            fb_add<R>(px + 1, nd.lighting.y * weight);
+            fb_add<R>(px + 2, nd.lighting.z * weight);
         }
-        count_hits(stats, level, valid && nd.hit);
-        if constexpr ((SF & SF_REFLECTIVE) != 0)
-            queue_push(out_q, valid && nd.has_reflect, nd.over_point, nd.reflectv, weight * nd.reflect_factor, pixel, stats);
-        if constexpr ((SF & SF_TRANSPARENT) != 0)
-            queue_push(out_q, valid && nd.has_refract, nd.under_point, nd.refract_dir, weight * nd.refract_factor, pixel, stats);
     }
+    count_hits(stats, blockIdx.x + blockIdx.y, level, valid && nd.hit);
+    const uint32_t sub = (blockIdx.x + blockIdx.y) & out_q.sub_mask;
+    if constexpr ((SF & SF_REFLECTIVE) != 0)
+        queue_push(out_q, sub, valid && nd.has_reflect, nd.over_point, nd.reflectv, weight * nd.reflect_factor, pixel, stats);
+    if constexpr ((SF & SF_TRANSPARENT) != 0)
+        queue_push(out_q, sub, valid && nd.has_refract, nd.under_point, nd.refract_dir, weight * nd.refract_factor, pixel, stats);
 }
 
 template <typename R>
@@ -255,10 +258,10 @@ hipError_t Launch<R>::primary_camera(uint32_t sf, hipStream_t stream, const Came
 }
 
 template <typename R>
-hipError_t Launch<R>::primary_rays(uint32_t sf, uint32_t grid, hipStream_t stream, const SceneDev<R> &scene,
-                                   const double *rays, uint32_t n, uint32_t remaining, R *fb, const QueueDev<R> &out_q,
-                                   StatShard *stats)
+hipError_t Launch<R>::primary_rays(uint32_t sf, hipStream_t stream, const SceneDev<R> &scene, const double *rays,
+                                   uint32_t n, uint32_t remaining, R *fb, const QueueDev<R> &out_q, StatShard *stats)
 {
+    const uint32_t grid = (n + kBlock - 1) / kBlock;
 #define RTX_CALL(SFV)                                                                                           \
     hipLaunchKernelGGL((k_primary_rays<R, SFV | SF_PATTERN>), dim3(grid), dim3(kBlock), 0, stream, scene, rays, n, \
                        remaining, fb, out_q, stats)
@@ -282,14 +285,14 @@ hipError_t Launch<R>::frame_begin(hipStream_t stream, const CameraDev<R> *cam, c
 }
 
 template <typename R>
-hipError_t Launch<R>::bounce(uint32_t sf, uint32_t grid, hipStream_t stream, const SceneDev<R> &scene,
-                             const QueueDev<R> &in_q, const QueueDev<R> &out_q, uint32_t remaining, uint32_t level,
-                             R *fb, StatShard *stats)
+hipError_t Launch<R>::bounce(uint32_t sf, hipStream_t stream, const SceneDev<R> &scene, const QueueDev<R> &in_q,
+                             const QueueDev<R> &out_q, uint32_t remaining, uint32_t level, R *fb, StatShard *stats)
 {
-    if ((sf & (SF_REFLECTIVE | SF_TRANSPARENT)) == 0) return hipSuccess;  // nothing can be queued
-#define RTX_CALL(SFV)                                                                                         \
-    if constexpr (((SFV) & (SF_REFLECTIVE | SF_TRANSPARENT)) != 0)                                            \
-        hipLaunchKernelGGL((k_bounce<R, SFV | SF_PATTERN>), dim3(grid), dim3(kBlock), 0, stream, scene, in_q, \
+    if ((sf & (SF_REFLECTIVE | SF_TRANSPARENT)) == 0 || in_q.cap_sub == 0) return hipSuccess;  // nothing can be queued
+    const dim3 grid((in_q.cap_sub + kBlock - 1) / kBlock, in_q.sub_mask + 1);
+#define RTX_CALL(SFV)                                                                                   \
+    if constexpr (((SFV) & (SF_REFLECTIVE | SF_TRANSPARENT)) != 0)                                      \
+        hipLaunchKernelGGL((k_bounce<R, SFV | SF_PATTERN>), grid, dim3(kBlock), 0, stream, scene, in_q, \
                            out_q, remaining, level, fb, stats)
     RTX_SF_SWITCH(sf, RTX_CALL)
 #undef RTX_CALL

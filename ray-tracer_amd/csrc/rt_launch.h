@@ -10,9 +10,17 @@
 
 namespace rtx {
 
-// Threads per workgroup and the persistent grid every launch uses: the kernels walk their
-// work with a grid-stride loop, so the grid is sized to the chip, not to the frame.
+// Threads per workgroup.  The render kernels handle one ray per thread without a loop, which
+// keeps loop-carried state out of the scalar registers the object records need.
 constexpr uint32_t kBlock = 256;
+
+// Workgroups of the camera kernel for n_rows rows of hsize pixels: a wave takes one 64-pixel
+// row segment, a workgroup four of them.
+inline uint64_t camera_blocks(uint32_t hsize, uint64_t n_rows)
+{
+    const uint64_t segs = (uint64_t)((hsize + 63u) / 64u) * n_rows;
+    return (segs + kBlock / 64 - 1) / (kBlock / 64);
+}
 
 template <typename R>
 struct Launch {
@@ -22,9 +30,8 @@ struct Launch {
                                      const PrimScene<R> &prim, uint32_t row0, uint32_t n_rows, uint32_t remaining, R *fb,
                                      const QueueDev<R> &out_q, StatShard *stats);
     // The same for rays[0..n) supplied by the caller (6 doubles each), result at fb[3 * k].
-    static hipError_t primary_rays(uint32_t sf, uint32_t grid, hipStream_t stream, const SceneDev<R> &scene,
-                                   const double *rays, uint32_t n, uint32_t remaining, R *fb, const QueueDev<R> &out_q,
-                                   StatShard *stats);
+    static hipError_t primary_rays(uint32_t sf, hipStream_t stream, const SceneDev<R> &scene, const double *rays,
+                                   uint32_t n, uint32_t remaining, R *fb, const QueueDev<R> &out_q, StatShard *stats);
     // First kernel of every frame: clears the two counter arrays and, for camera renders
     // (cam != nullptr), fills the per-frame primary-ray tables `prim` (device memory sized by
     // the caller) from the scene tables and the camera origin.
@@ -32,10 +39,9 @@ struct Launch {
                                   const PrimScene<R> &prim, uint32_t *zero_a, uint32_t n_a, uint32_t *zero_b,
                                   uint32_t n_b);
     // One recursion level below the primary rays: consume in_q, add weight * lighting into
-    // fb, queue the next level.
-    static hipError_t bounce(uint32_t sf, uint32_t grid, hipStream_t stream, const SceneDev<R> &scene,
-                             const QueueDev<R> &in_q, const QueueDev<R> &out_q, uint32_t remaining, uint32_t level,
-                             R *fb, StatShard *stats);
+    // fb, queue the next level.  The grid covers the worst-case length of every sub-queue.
+    static hipError_t bounce(uint32_t sf, hipStream_t stream, const SceneDev<R> &scene, const QueueDev<R> &in_q,
+                             const QueueDev<R> &out_q, uint32_t remaining, uint32_t level, R *fb, StatShard *stats);
     // Primary rays only (no tracing): out[6*k..] = origin, direction.
     static hipError_t raygen(uint32_t grid, hipStream_t stream, const CameraDev<R> &cam, uint32_t pix_begin,
                              uint32_t n_pix, double *out);

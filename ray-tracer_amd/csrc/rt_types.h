@@ -133,12 +133,17 @@ struct CameraDev {
 };
 
 // Secondary-ray queue: 8 scalars per entry (origin, direction, path weight, pixel index).
+// A queue is split into n_sub sub-queues of cap_sub entries, each with its own length counter:
+// appends to ONE counter from every wave of the chip serialise (about 11 ns each on MI355X),
+// appends spread over >= 256 counters do not.  A workgroup appends to the sub-queue its index
+// selects, so the worst-case fill of every sub-queue is known on the host.
+constexpr uint32_t kCountStride = 32;  // words between two counters: one 128-byte line each
 template <typename R>
 struct QueueDev {
-    R *rec;
-    uint32_t *count;
-    uint32_t capacity;
-    uint32_t pad;
+    R *rec;            // sub-queue q occupies entries [q * cap_sub, (q + 1) * cap_sub)
+    uint32_t *count;   // length of sub-queue q at count[q * kCountStride]
+    uint32_t cap_sub;  // entries per sub-queue (0: nothing may be appended)
+    uint32_t sub_mask; // n_sub - 1, n_sub a power of two
 };
 
 // Per-level counters, one block of shards per render call (summed on the host).

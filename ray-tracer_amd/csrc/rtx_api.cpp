@@ -60,8 +60,9 @@ struct Slot {
     size_t aux_bytes = 0;
     void *prim = nullptr;       // per-frame primary-ray tables
     size_t prim_bytes = 0;
-    uint32_t *counts = nullptr; // queue counters, kMaxLevels + 1 per chunk
+    uint32_t *counts = nullptr; // sub-queue length counters: per chunk, per level, per sub-queue
     size_t counts_n = 0;
+    uint32_t n_sub = 1;         // sub-queues per queue of the last frame enqueued
     StatShard *shards = nullptr;
     hipEvent_t done = nullptr;  // recorded when a call returns with work still in flight
     bool pending = false;
@@ -308,63 +309,91 @@ uint32_t grid_for(const rtx_context *ctx, uint64_t n)
     return (uint32_t)blocks;
 }
 
-// Worst-case number of rays on recursion level L for one primary ray: every hit can spawn a
-// reflection ray (if any object reflects) and a refraction ray (if any object is transparent).
-uint64_t level_growth(uint32_t sf, uint32_t level)
-{
-    const uint64_t g = ((sf & SF_REFLECTIVE) ? 1u : 0u) + ((sf & SF_TRANSPARENT) ? 1u : 0u);
-    uint64_t v = 1;
-    for (uint32_t i = 0; i < level; ++i) v *= g;
-    return v;
-}
+// Most children one color_at node can queue: a reflection ray if any object reflects, a
+// refraction ray if any object is transparent.
+uint64_t children_per_hit(uint32_t sf) { return ((sf & SF_REFLECTIVE) ? 1u : 0u) + ((sf & SF_TRANSPARENT) ? 1u : 0u); }
 
 struct FramePlan {
-    uint32_t levels = 0;         // bounce launches per chunk
-    uint64_t cap_odd = 0, cap_even = 0;  // worst-case entries per primary ray in the queue of odd / even levels
-    uint64_t chunk_pix = 0;      // primary rays per chunk
+    uint32_t levels = 0;        // bounce launches per chunk
+    uint32_t n_sub = 1;         // sub-queues per queue (power of two)
+    uint64_t chunk_units = 0;   // rows (camera renders) or rays (batches) per chunk
+    uint64_t cap_sub[kMaxLevels + 2] = {};  // entries per sub-queue of the queue that feeds level L
+    uint64_t odd_entries = 0, even_entries = 0;  // entries of the two ping-pong buffers
+    size_t bytes = 0;
 };
 
-// Split [0, n_pix) into chunks so that both ping-pong queues, sized for the worst case, fit
-// the workspace limit.  `align` keeps chunks on row boundaries for camera renders.
+// Queue sizes for chunks of `units` rows / rays.  Workgroup b of the primary kernel appends to
+// sub-queue b mod n_sub and each of its 256 threads queues at most g children, which bounds
+// the level-1 sub-queues; a bounce launch feeds every output sub-queue from exactly
+// ceil(cap_sub / 256) workgroups, which bounds the next level the same way.
 template <typename R>
-int plan_frame(const rtx_context *ctx, uint32_t sf, uint32_t max_depth, uint64_t n_pix, uint64_t align, FramePlan *p)
+void size_queues(uint32_t sf, uint32_t levels, uint32_t hsize, uint64_t units, FramePlan *p)
+{
+    const uint64_t g = children_per_hit(sf);
+    const uint64_t blocks0 = hsize ? camera_blocks(hsize, units) : (units + kBlock - 1) / kBlock;
+    uint32_t n_sub = 1;
+    while (n_sub < 256 && (uint64_t)n_sub * 2 * 8 <= blocks0) n_sub *= 2;
+    p->levels = levels;
+    p->n_sub = n_sub;
+    p->chunk_units = units;
+    p->odd_entries = p->even_entries = 0;
+    for (auto &c : p->cap_sub) c = 0;
+    uint64_t cap = ((blocks0 + n_sub - 1) / n_sub) * kBlock * g;
+    for (uint32_t L = 1; L <= levels; ++L) {
+        p->cap_sub[L] = cap;
+        uint64_t &tot = (L & 1) ? p->odd_entries : p->even_entries;
+        tot = std::max(tot, cap * n_sub);
+        cap = ((cap + kBlock - 1) / kBlock) * kBlock * g;
+    }
+    p->bytes = (size_t)((p->odd_entries + p->even_entries) * 8 * sizeof(R));
+}
+
+// Split the frame into chunks of whole rows (or of rays, hsize = 0) so that both ping-pong
+// queues, sized for the worst case, fit the workspace limit.
+template <typename R>
+int plan_frame(const rtx_context *ctx, uint32_t sf, uint32_t max_depth, uint32_t hsize, uint64_t n_units, FramePlan *p)
 {
     if (max_depth >= kMaxLevels) return fail(RTX_ERR_INVALID, "max_depth %u is not supported (limit %u)", max_depth, kMaxLevels - 1);
-    const bool secondary = (sf & (SF_REFLECTIVE | SF_TRANSPARENT)) != 0 && max_depth > 0;
-    p->levels = secondary ? max_depth : 0;
-    p->cap_odd = p->cap_even = 0;
-    for (uint32_t L = 1; L <= p->levels; ++L) {
-        uint64_t &cap = (L & 1) ? p->cap_odd : p->cap_even;
-        cap = std::max(cap, level_growth(sf, L));
+    const bool secondary = children_per_hit(sf) != 0 && max_depth > 0;
+    const uint32_t levels = secondary ? max_depth : 0;
+    // one launch covers at most 2^31 - 256 primary rays
+    const uint64_t max_units = hsize ? std::max<uint64_t>(1, 0x7fffff00ull / hsize) : 0x7fffff00ull;
+    auto fits = [&](uint64_t units) {
+        size_queues<R>(sf, levels, hsize, units, p);
+        if (p->bytes > ctx->workspace_limit) return false;
+        for (uint32_t L = 1; L <= levels; ++L)
+            if (p->cap_sub[L] > 0x7fffff00ull) return false;  // sub-queue slots are indexed with 32 bits
+        return true;
+    };
+    uint64_t hi = std::min<uint64_t>(std::max<uint64_t>(n_units, 1), max_units);
+    if (!fits(hi)) {
+        if (!fits(1)) return fail(RTX_ERR_INVALID, "workspace limit too small for one row of this frame");
+        uint64_t lo = 1;  // fits(lo) holds, fits(hi) does not
+        while (hi - lo > 1) {
+            const uint64_t mid = lo + (hi - lo) / 2;
+            if (fits(mid)) lo = mid; else hi = mid;
+        }
+        (void)fits(lo);
     }
-    const uint64_t per_pix = (p->cap_odd + p->cap_even) * 8 * sizeof(R);
-    uint64_t chunk = n_pix;
-    if (per_pix) {
-        chunk = std::min<uint64_t>(chunk, ctx->workspace_limit / per_pix);
-        // queue slots are indexed with 32 bits
-        chunk = std::min<uint64_t>(chunk, 0xfffffff0ull / std::max(p->cap_odd, p->cap_even));
-    }
-    chunk = std::min<uint64_t>(chunk, 0x7fffff00ull);
-    if (align > 1) chunk = (chunk / align) * align;
-    if (chunk == 0) return fail(RTX_ERR_INVALID, "workspace limit too small for one row of this frame");
-    p->chunk_pix = chunk;
     return RTX_OK;
 }
 
-// Enqueue every kernel of one frame (or ray batch) on the slot's stream.
+// Enqueue every kernel of one frame (or ray batch) on the slot's stream.  Camera renders cover
+// n_units rows starting at row first_row; batches cover n_units rays of d_rays.
 template <typename R>
 int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Slot *slot, hipStream_t stream, const CameraDev<R> *cam,
-                  const double *d_rays, uint64_t first_pix, uint64_t n_pix, uint64_t align, uint32_t max_depth, R *d_fb,
+                  const double *d_rays, uint32_t first_row, uint64_t n_units, uint32_t max_depth, R *d_fb,
                   rtx_progress_fn progress, void *user, bool timed, uint32_t *n_chunks_out, uint32_t *n_launch_out)
 {
     FramePlan plan;
-    int rc = plan_frame<R>(ctx, scene->sf, max_depth, n_pix, align, &plan);
+    const uint32_t W = cam ? cam->hsize : 0;
+    int rc = plan_frame<R>(ctx, scene->sf, max_depth, W, n_units, &plan);
     if (rc) return rc;
-    const uint32_t n_chunks = (uint32_t)((n_pix + plan.chunk_pix - 1) / plan.chunk_pix);
-    const uint64_t cap_odd = plan.cap_odd * plan.chunk_pix, cap_even = plan.cap_even * plan.chunk_pix;
-    rc = grow(&slot->queues, &slot->queue_bytes, (size_t)((cap_odd + cap_even) * 8 * sizeof(R)));
+    const uint32_t n_chunks = (uint32_t)((n_units + plan.chunk_units - 1) / plan.chunk_units);
+    rc = grow(&slot->queues, &slot->queue_bytes, plan.bytes);
     if (rc) return rc;
-    const size_t counts_need = (size_t)n_chunks * (kMaxLevels + 1);
+    const size_t counts_per_chunk = (size_t)(kMaxLevels + 1) * plan.n_sub * kCountStride;
+    const size_t counts_need = (size_t)std::max<uint32_t>(n_chunks, 1) * counts_per_chunk;
     if (counts_need > slot->counts_n) {
         if (slot->counts) HIP_TRY(hipFree(slot->counts));
         slot->counts = nullptr;
@@ -372,6 +401,7 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Slot *slot, hipStrea
         HIP_TRY(hipMalloc((void **)&slot->counts, counts_need * sizeof(uint32_t)));
         slot->counts_n = counts_need;
     }
+    slot->n_sub = plan.n_sub;
     if (timed) HIP_TRY(hipEventRecord(slot->ev[0], stream));
 
     // primary-ray tables: one entry per object, rebuilt every frame from the camera origin
@@ -397,43 +427,43 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Slot *slot, hipStrea
                                    (uint32_t)(sizeof(StatShard) * kStatShards / sizeof(uint32_t))));
 
     R *q_odd = (R *)slot->queues;
-    R *q_even = q_odd + cap_odd * 8;
+    R *q_even = q_odd + plan.odd_entries * 8;
     const SceneDev<R> &S = scene_dev<R>(scene);
     uint32_t launches = 0;
+    uint64_t done = 0;
     for (uint32_t c = 0; c < n_chunks; ++c) {
-        const uint64_t k0 = (uint64_t)c * plan.chunk_pix;
-        const uint32_t n = (uint32_t)std::min<uint64_t>(plan.chunk_pix, n_pix - k0);
-        uint32_t *counts = slot->counts + (size_t)c * (kMaxLevels + 1);
+        const uint64_t u0 = (uint64_t)c * plan.chunk_units;
+        const uint64_t units = std::min<uint64_t>(plan.chunk_units, n_units - u0);
+        uint32_t *counts = slot->counts + (size_t)c * counts_per_chunk;
         auto queue_at = [&](uint32_t level) {
             QueueDev<R> q;
             q.rec = (level & 1) ? q_odd : q_even;
-            q.count = counts + level;
-            q.capacity = (uint32_t)((level & 1) ? cap_odd : cap_even);
-            q.pad = 0;
-            if (level > plan.levels) q.capacity = 0;
+            q.count = counts + (size_t)level * plan.n_sub * kCountStride;
+            q.cap_sub = level <= plan.levels ? (uint32_t)plan.cap_sub[level] : 0u;
+            q.sub_mask = plan.n_sub - 1;
             return q;
         };
+        const uint64_t k0 = cam ? u0 * W : u0;  // first primary ray of the chunk
         R *fb = d_fb + k0 * 3;
         if (timed && c == 0) HIP_TRY(hipEventRecord(slot->ev[2], stream));
         if (cam) {
-            const uint32_t W = cam->hsize;
-            HIP_TRY(Launch<R>::primary_camera(scene->sf, stream, *cam, S, prim, (uint32_t)((first_pix + k0) / W), n / W,
+            HIP_TRY(Launch<R>::primary_camera(scene->sf, stream, *cam, S, prim, first_row + (uint32_t)u0, (uint32_t)units,
                                               max_depth, fb, queue_at(1), slot->shards));
         } else {
-            HIP_TRY(Launch<R>::primary_rays(scene->sf, grid_for(ctx, n), stream, S, d_rays + k0 * 6, n, max_depth, fb,
-                                            queue_at(1), slot->shards));
+            HIP_TRY(Launch<R>::primary_rays(scene->sf, stream, S, d_rays + k0 * 6, (uint32_t)units, max_depth, fb, queue_at(1),
+                                            slot->shards));
         }
         if (timed && c == 0) HIP_TRY(hipEventRecord(slot->ev[3], stream));
         ++launches;
         for (uint32_t L = 1; L <= plan.levels; ++L) {
-            const uint64_t worst = std::min<uint64_t>((uint64_t)n * level_growth(scene->sf, L), 0xffffffffull);
-            HIP_TRY(Launch<R>::bounce(scene->sf, grid_for(ctx, worst), stream, S, queue_at(L), queue_at(L + 1),
-                                      max_depth - L, L, fb, slot->shards));
+            HIP_TRY(Launch<R>::bounce(scene->sf, stream, S, queue_at(L), queue_at(L + 1), max_depth - L, L, fb,
+                                      slot->shards));
             ++launches;
         }
+        done += cam ? units * W : units;
         if (progress) {
             HIP_TRY(hipStreamSynchronize(stream));
-            progress(k0 + n, user);
+            progress(done, user);
         }
     }
     if (timed) HIP_TRY(hipEventRecord(slot->ev[1], stream));
@@ -447,7 +477,8 @@ int collect_stats(Slot *slot, uint32_t n_chunks, uint64_t n_primary, bool timed,
 {
     std::vector<StatShard> shards(kStatShards);
     HIP_TRY(hipMemcpy(shards.data(), slot->shards, sizeof(StatShard) * kStatShards, hipMemcpyDeviceToHost));
-    std::vector<uint32_t> counts((size_t)n_chunks * (kMaxLevels + 1));
+    const size_t counts_per_chunk = (size_t)(kMaxLevels + 1) * slot->n_sub * kCountStride;
+    std::vector<uint32_t> counts((size_t)n_chunks * counts_per_chunk);
     HIP_TRY(hipMemcpy(counts.data(), slot->counts, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     uint64_t overflow = 0;
     for (auto &s : shards) overflow += s.overflow;
@@ -456,7 +487,9 @@ int collect_stats(Slot *slot, uint32_t n_chunks, uint64_t n_primary, bool timed,
     std::memset(stats->rays_per_level, 0, sizeof stats->rays_per_level);
     stats->rays_per_level[0] = n_primary;
     for (uint32_t c = 0; c < n_chunks; ++c)
-        for (uint32_t L = 1; L < kMaxLevels; ++L) stats->rays_per_level[L] += counts[(size_t)c * (kMaxLevels + 1) + L];
+        for (uint32_t L = 1; L < kMaxLevels; ++L)
+            for (uint32_t q = 0; q < slot->n_sub; ++q)
+                stats->rays_per_level[L] += counts[c * counts_per_chunk + ((size_t)L * slot->n_sub + q) * kCountStride];
     stats->color_rays = 0;
     for (uint32_t L = 0; L < kMaxLevels; ++L) stats->color_rays += stats->rays_per_level[L];
     stats->shadow_rays = 0;
@@ -515,7 +548,7 @@ int render_impl(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_desc 
     const CameraDev<R> cd = make_camera<R>(cam);
     uint32_t n_chunks = 0, n_launch = 0;
     const bool sync = host_out != nullptr || stats != nullptr;
-    rc = enqueue_frame<R>(ctx, scene, slot, stream, &cd, nullptr, (uint64_t)row_begin * W, n_pix, W, max_depth, d_fb,
+    rc = enqueue_frame<R>(ctx, scene, slot, stream, &cd, nullptr, row_begin, row_end - row_begin, max_depth, d_fb,
                           progress, user, sync, &n_chunks, &n_launch);
     if (rc) return rc;
     if (!sync) {
@@ -556,7 +589,7 @@ int trace_impl(rtx_context *ctx, const rtx_scene *scene, const double *rays, siz
     hipStream_t stream = slot->stream;
     HIP_TRY(hipMemcpyAsync(slot->aux, rays, ray_bytes, hipMemcpyHostToDevice, stream));
     uint32_t n_chunks = 0, n_launch = 0;
-    rc = enqueue_frame<R>(ctx, scene, slot, stream, nullptr, (const double *)slot->aux, 0, n, 1, max_depth, (R *)slot->fb,
+    rc = enqueue_frame<R>(ctx, scene, slot, stream, nullptr, (const double *)slot->aux, 0, n, max_depth, (R *)slot->fb,
                           nullptr, nullptr, true, &n_chunks, &n_launch);
     if (rc) return rc;
     std::vector<R> tmp;
@@ -603,6 +636,11 @@ int rtx_context_create(int device_id, rtx_context **out)
     ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     ctx->clock_mhz = prop.clockRate / 1000;
     ctx->name = prop.name;
+    // Queues are sized for the worst case (every hit reflects and refracts down to the depth
+    // limit): a 4K depth-5 frame of a scene with glass needs about 26 GB.  A sixth of the device
+    // memory (48 GB of 288) lets such a frame run as one chunk and leaves room for several
+    // concurrent render calls.
+    ctx->workspace_limit = std::max<size_t>((size_t)8 << 30, prop.totalGlobalMem / 6);
     if (const char *e = std::getenv("RTX_BLOCKS_PER_CU")) {
         int v = std::atoi(e);
         if (v >= 1 && v <= 64) ctx->blocks_per_cu = (uint32_t)v;
