@@ -29,6 +29,7 @@ namespace rtx {
 // ---- scalar helpers -----------------------------------------------------------------
 template <typename R> struct Num;
 template <> struct Num<double> {
+    static constexpr bool exact = true;                      // expression-by-expression restatement
     static constexpr double eps = 0.00001;                   // src/utils.rs:1
     static constexpr double big = 1.7976931348623157e308;    // f64::MAX
     static constexpr double inf = __builtin_huge_val();
@@ -40,13 +41,17 @@ template <> struct Num<double> {
     static RT_DEV double max_(double a, double b) { return __builtin_fmax(a, b); }
     static RT_DEV double min_(double a, double b) { return __builtin_fmin(a, b); }
 };
+// The float instantiation is the fast path: it has no bit-parity contract (8-bit colours within
+// 1/255 of the f64 result on >= 99.9 % of the pixels), so it uses the hardware's 1-ulp
+// reciprocal, square root, exp2 and log2, and formulations that stay accurate in 24 bits.
 template <> struct Num<float> {
+    static constexpr bool exact = false;
     static constexpr float eps = 0.00001f;
     static constexpr float big = 3.402823466e38f;
     static constexpr float inf = __builtin_huge_valf();
-    static RT_DEV float sqrt_(float x) { return __builtin_sqrtf(x); }
-    static RT_DEV float div(float a, float b) { return a / b; }
-    static RT_DEV float pow_(float a, float b) { return powf(a, b); }
+    static RT_DEV float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
+    static RT_DEV float div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+    static RT_DEV float pow_(float a, float b) { return __builtin_amdgcn_exp2f(b * __builtin_amdgcn_logf(a)); }
     static RT_DEV float abs_(float x) { return __builtin_fabsf(x); }
     static RT_DEV float floor_(float x) { return __builtin_floorf(x); }
     static RT_DEV float max_(float a, float b) { return __builtin_fmaxf(a, b); }
@@ -60,8 +65,14 @@ template <typename R> RT_DEV R dot3(V3<R> a, V3<R> b) { return (a.x * b.x + a.y 
 // src/matrices/tuples.rs:58-73: magnitude, then three divisions
 template <typename R> RT_DEV V3<R> normalize3(V3<R> a)
 {
-    const R mag = Num<R>::sqrt_((a.x * a.x + a.y * a.y) + a.z * a.z);
-    return { Num<R>::div(a.x, mag), Num<R>::div(a.y, mag), Num<R>::div(a.z, mag) };
+    const R m2 = (a.x * a.x + a.y * a.y) + a.z * a.z;
+    if constexpr (Num<R>::exact) {
+        const R mag = Num<R>::sqrt_(m2);
+        return { Num<R>::div(a.x, mag), Num<R>::div(a.y, mag), Num<R>::div(a.z, mag) };
+    } else {
+        const R r = __builtin_amdgcn_rsqf(m2);
+        return { a.x * r, a.y * r, a.z * r };
+    }
 }
 // src/matrices/matrix4.rs:172-193 for a point (w = 1) and a vector (w = 0); m = 3 rows x 4
 template <typename R> RT_DEV V3<R> xform_point(const R *m, V3<R> p)
@@ -86,6 +97,22 @@ template <typename R> RT_DEV V3<R> xform_vector(const R *m, V3<R> v)
 // src/shapes/spheres.rs:24-42; c = (origin . origin) - 1
 template <typename R, typename Emit> RT_DEV void isect_sphere(V3<R> o, V3<R> d, R c, Emit &&emit)
 {
+    if constexpr (!Num<R>::exact) {
+        // b^2 - 4ac cancels catastrophically in 24 bits once the sphere is far from the ray
+        // origin.  Go through the point of the ray closest to the centre instead: with
+        // h = d.o and l = o - (h/a) d, the roots are -h/a -+ sqrt((1 - l.l) / a).
+        const R a = dot3(d, d);
+        const R inv_a = __builtin_amdgcn_rcpf(a);
+        const R ha = dot3(d, o) * inv_a;
+        const V3<R> l = { o.x - ha * d.x, o.y - ha * d.y, o.z - ha * d.z };
+        const R rem = R(1) - dot3(l, l);
+        if (!(rem < R(0))) {
+            const R s = Num<R>::sqrt_(rem * inv_a);
+            emit(-ha - s);
+            emit(-ha + s);
+        }
+        return;
+    }
     R a = dot3(d, d);
     R b = R(2) * dot3(d, o);
     R disc = b * b - ((R(4) * a) * c);
@@ -177,6 +204,22 @@ RT_DEV void isect_cylinder(V3<R> o, V3<R> o2, R c, V3<R> d, R ymin, R ymax, bool
         isect_caps<R, false>(o, d, ymin, ymax, closed, emit);
         return;
     }
+    if constexpr (!Num<R>::exact) {
+        // the sphere's closest-point form in the xz plane
+        const R inv_a = __builtin_amdgcn_rcpf(a);
+        const R ha = (o.x * d.x + o.z * d.z) * inv_a;
+        const R lx = o.x - ha * d.x, lz = o.z - ha * d.z;
+        const R rem = R(1) - (lx * lx + lz * lz);
+        if (rem < R(0)) return;
+        const R s = Num<R>::sqrt_(rem * inv_a);
+        const R t0 = -ha - s, t1 = -ha + s;
+        const R y0 = o.y + t0 * d.y;
+        if (ymin < y0 && y0 < ymax) emit(t0);
+        const R y1 = o.y + t1 * d.y;
+        if (ymin < y1 && y1 < ymax) emit(t1);
+        isect_caps<R, false>(o, d, ymin, ymax, closed, emit);
+        return;
+    }
     R b = o2.x * d.x + o2.z * d.z;
     if (!isect_wall(a, b, c, o, d, ymin, ymax, emit)) return;
     isect_caps<R, false>(o, d, ymin, ymax, closed, emit);
@@ -185,6 +228,32 @@ RT_DEV void isect_cylinder(V3<R> o, V3<R> o2, R c, V3<R> d, R ymin, R ymax, bool
 template <typename R, typename Emit>
 RT_DEV void isect_cone(V3<R> o, V3<R> o2, R c, V3<R> d, R ymin, R ymax, bool closed, Emit &&emit)
 {
+    if constexpr (!Num<R>::exact) {
+        // The cone's quadratic form is indefinite, so there is no closest-point rewrite; its
+        // coefficients and roots are evaluated in f64 from the f32 object-space ray.
+        const double ox = o.x, oy = o.y, oz = o.z, dx = d.x, dy = d.y, dz = d.z;
+        const double a = (dx * dx - dy * dy) + dz * dz;
+        const double b = 2.0 * ((ox * dx - oy * dy) + oz * dz);
+        const double c = (ox * ox - oy * oy) + oz * oz;
+        const bool a0 = __builtin_fabs(a) < 0.00001, b0 = __builtin_fabs(b) < 0.00001;
+        if (!(a0 && b0)) {
+            if (a0) {
+                emit(R(-c / (2.0 * b)));
+            } else {
+                const double disc = b * b - 4.0 * a * c;
+                if (disc < 0.0) return;
+                const double sq = __builtin_sqrt(disc);
+                double t0 = (-b - sq) / (2.0 * a), t1 = (-b + sq) / (2.0 * a);
+                if (t0 > t1) { const double tmp = t0; t0 = t1; t1 = tmp; }
+                const double y0 = oy + t0 * dy;
+                if (ymin < y0 && y0 < ymax) emit(R(t0));
+                const double y1 = oy + t1 * dy;
+                if (ymin < y1 && y1 < ymax) emit(R(t1));
+            }
+        }
+        isect_caps<R, true>(o, d, ymin, ymax, closed, emit);
+        return;
+    }
     R a = (d.x * d.x - d.y * d.y) + d.z * d.z;
     R b = (o2.x * d.x - o2.y * d.y) + o2.z * d.z;
     bool a0 = Num<R>::abs_(a) < Num<R>::eps;
@@ -600,8 +669,15 @@ RT_DEV Node<R> trace_node(const SceneDev<R> &S, const PrimScene<R> *P, V3<R> ro,
     R d2 = R(2) * dot3(rd, normalv);
     V3<R> reflectv = { rd.x - normalv.x * d2, rd.y - normalv.y * d2, rd.z - normalv.z * d2 };
     // Computations::new, world.rs:219-220
-    V3<R> over = { pt.x + normalv.x * Num<R>::eps, pt.y + normalv.y * Num<R>::eps, pt.z + normalv.z * Num<R>::eps };
-    V3<R> under = { pt.x - normalv.x * Num<R>::eps, pt.y - normalv.y * Num<R>::eps, pt.z - normalv.z * Num<R>::eps };
+    R off = Num<R>::eps;
+    if constexpr (!Num<R>::exact) {
+        // 1e-5 is below the spacing of floats beyond |p| ~ 100 and below the error of the hit point
+        // well before that: let the offset grow with the magnitude of the point
+        const R mag = Num<R>::max_(Num<R>::max_(Num<R>::abs_(pt.x), Num<R>::abs_(pt.y)), Num<R>::abs_(pt.z));
+        off = R(4) * Num<R>::eps * Num<R>::max_(R(1), mag);
+    }
+    V3<R> over = { pt.x + normalv.x * off, pt.y + normalv.y * off, pt.z + normalv.z * off };
+    V3<R> under = { pt.x - normalv.x * off, pt.y - normalv.y * off, pt.z - normalv.z * off };
 
     R n1 = R(1), n2 = R(1);
     if constexpr (TRACK) {

@@ -100,8 +100,11 @@ RT_DEV void primary_ray(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> ro, V
 // one pixel per lane, so its framebuffer stores cover one contiguous run.  There is no loop:
 // the camera block is dead once the ray exists, which leaves the scalar register file to the
 // object tables.  The intersection walk reads the per-frame primary tables.
+#ifndef RTX_CAMERA_ATTR
+#define RTX_CAMERA_ATTR
+#endif
 template <typename R, uint32_t SF>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock) RTX_CAMERA_ATTR
 k_primary_camera(CameraDev<R> cam, SceneDev<R> S, PrimScene<R> P, uint32_t row0, uint32_t n_rows, uint32_t segs_per_row,
                  uint32_t remaining, R *__restrict__ fb, QueueDev<R> out_q, StatShard *__restrict__ stats)
 {
