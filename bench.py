@@ -49,7 +49,8 @@ def parse_args():
     ap.add_argument("--objects", type=int, default=10000, help="object count of the random scene")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary scenes reported under 'extra'")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0,
+                    help="CPU work (seconds summed over threads) of the baseline sample")
     return ap.parse_args()
 
 
@@ -74,9 +75,13 @@ def host_threads():
     return max(1, min(n, 64))
 
 
-def cpu_baseline(scene_name, width, height, depth, objects, target_seconds):
+def cpu_baseline(scene_name, width, height, depth, objects, target_cpu_seconds):
     """The C restatement of the reference's render loop (oracle/), run reference-shaped:
-    10-row bands handed out dynamically to one thread per host core."""
+    10-row bands (src/scenes/camera.rs:177) handed out dynamically to one thread per host core.
+    The sample is about `target_cpu_seconds` of CPU work summed over the threads: whole frames
+    repeated when a frame is cheaper than that, a centred block of bands when it is dearer."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
     orc = entry.load_oracle()
     from ray_tracer_amd import scenes
     kw = dict(hsize=width, vsize=height)
@@ -84,29 +89,28 @@ def cpu_baseline(scene_name, width, height, depth, objects, target_seconds):
         kw["n_objects"] = objects
     world, cam = scenes.SCENES[scene_name](orc.api, **kw)
     threads = host_threads()
-    # calibrate on a few bands in the middle of the frame, then size the sample
-    import ctypes as C
-    cnt = (C.c_uint64 * 2)(0, 0)
     full = np.zeros((height, width, 3))
+    # calibrate on the band in the middle of the frame
+    cnt = (C.c_uint64 * 2)(0, 0)
     mid = (height // 2 // 10) * 10
     t0 = time.perf_counter()
     orc._check(orc._render_rows(cam.h, world.h, depth, mid, min(mid + 10, height), full.ctypes.data_as(orc._dp), cnt))
     per_row = (time.perf_counter() - t0) / max(1, min(mid + 10, height) - mid)
-    rows = int(min(height, max(10 * threads, (target_seconds * threads / max(per_row, 1e-9)) // 10 * 10)))
-    sample_cam = cam
-    if rows < height:
-        # centred block of whole bands of the same frame: orc_parallel_render walks a whole
-        # camera, so render rows [r0, r0 + rows) band by band through a thread pool instead
+    frame_cpu_s = per_row * height
+    if frame_cpu_s >= target_cpu_seconds:
+        rows = int(max(10 * threads, (target_cpu_seconds / per_row) // 10 * 10))
+        rows = min(rows, height)
         r0 = ((height - rows) // 2 // 10) * 10
+        repeats = 1
     else:
         r0, rows = 0, height
-    from concurrent.futures import ThreadPoolExecutor
-    bands = [(b, min(b + 10, r0 + rows)) for b in range(r0, r0 + rows, 10)]
+        repeats = int(min(1000, max(1, round(target_cpu_seconds / max(frame_cpu_s, 1e-9)))))
+    bands = [(b, min(b + 10, r0 + rows)) for _ in range(repeats) for b in range(r0, r0 + rows, 10)]
     counters = [(C.c_uint64 * 2)(0, 0) for _ in bands]
 
     def work(i):
         a, b = bands[i]
-        orc._check(orc._render_rows(sample_cam.h, world.h, depth, a, b, full.ctypes.data_as(orc._dp), counters[i]))
+        orc._check(orc._render_rows(cam.h, world.h, depth, a, b, full.ctypes.data_as(orc._dp), counters[i]))
 
     t0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=threads) as pool:
@@ -118,10 +122,25 @@ def cpu_baseline(scene_name, width, height, depth, objects, target_seconds):
         "unit": "Mrays/s",
         "cores": threads,
         "kind": "port",
-        "sample": "rows [%d, %d) of the %dx%d %s frame, depth %d: %d rays in %.2f s; C restatement of the "
-                  "reference's render loop in 10-row bands, not the Rust binary" % (r0, r0 + rows, width, height, scene_name,
-                                                                                  depth, rays, dt),
+        "sample": "rows [%d, %d) of the %dx%d %s frame, depth %d, %d time(s): %d rays in %.2f s wall on %d threads; C "
+                  "restatement of the reference's render loop in 10-row bands, not the Rust binary"
+                  % (r0, r0 + rows, width, height, scene_name, depth, repeats, rays, dt, threads),
     }
+
+
+def measured_traffic(scene_name, precision, width, height, kernel_prefix):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of
+    this workload (profiles/), or None when there is no such profile.  FETCH_SIZE and WRITE_SIZE
+    count KiB; FETCH_SIZE is doubled as gfx950 tallies 128-byte read requests at 64 bytes."""
+    path = os.path.join(ROOT, "profiles", "r01_%s_%dx%d_%s_pmc.json" % (scene_name, width, height, precision))
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        pmc = json.load(f)
+    for kernel, counters in pmc.items():
+        if kernel_prefix in kernel and "WRITE_SIZE" in counters and "FETCH_SIZE" in counters:
+            return (2.0 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024.0
+    return None
 
 
 def main():
@@ -242,12 +261,13 @@ def main():
             },
             "roofline": {
                 "bound": "valu",
-                "kernel": "k_primary" if single_kernel else "k_primary + k_bounce (all levels)",
+                "kernel": "k_primary_camera" if single_kernel else "k_primary_camera + k_bounce (all levels)",
                 "achieved": achieved,
                 "peak": peak,
                 "unit": "TFLOP/s",
                 "frac": achieved / peak,
-                "traffic": None,
+                "traffic": measured_traffic(args.scene, args.precision, args.width, args.height, "k_primary_camera")
+                if single_kernel and n_gpus == 1 else None,
                 "kernel_ms": k_ms,
                 "algorithmic_flops_per_launch": flops_tile,
                 "hbm_write_GBps": n_pix_tile * 3 * tile.element_size() / (k_ms * 1e-3) / 1e9,

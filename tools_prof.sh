@@ -25,8 +25,13 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         agg[row["Kernel_Name"][:60]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+import json
+means = {}
 for k, d in agg.items():
     print("== counters (mean per dispatch)", k)
+    means[k] = {}
     for c, v in sorted(d.items()):
         print("   %-28s %.6g  (n=%d)" % (c, sum(v) / len(v), len(v)))
+        means[k][c] = sum(v) / len(v)
+json.dump(means, open(out + "/pmc.json", "w"), indent=1, sort_keys=True)
 PY
