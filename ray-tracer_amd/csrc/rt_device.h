@@ -671,10 +671,13 @@ RT_DEV Node<R> trace_node(const SceneDev<R> &S, const PrimScene<R> *P, V3<R> ro,
     // Computations::new, world.rs:219-220
     R off = Num<R>::eps;
     if constexpr (!Num<R>::exact) {
-        // 1e-5 is below the spacing of floats beyond |p| ~ 100 and below the error of the hit point
-        // well before that: let the offset grow with the magnitude of the point
+        // The reference's 1e-5 is kept wherever floats resolve it (|p| <= 4: at least 20 ulp);
+        // beyond that it grows in proportion to |p|, since 1e-5 falls below the error of an f32
+        // hit point and, past |p| ~ 100, below the spacing of floats.  Inflating it near the
+        // origin as well is visible: a ray refracted into a sphere at grazing incidence starts
+        // deeper and lands 30-100 offsets away from where the reference's ray does.
         const R mag = Num<R>::max_(Num<R>::max_(Num<R>::abs_(pt.x), Num<R>::abs_(pt.y)), Num<R>::abs_(pt.z));
-        off = R(4) * Num<R>::eps * Num<R>::max_(R(1), mag);
+        off = Num<R>::eps * Num<R>::max_(R(1), mag * R(0.25));
     }
     V3<R> over = { pt.x + normalv.x * off, pt.y + normalv.y * off, pt.z + normalv.z * off };
     V3<R> under = { pt.x - normalv.x * off, pt.y - normalv.y * off, pt.z - normalv.z * off };

@@ -48,6 +48,10 @@ RT_DEV void queue_push(const QueueDev<R> &q, uint32_t sub, bool active, V3<R> o,
             using V2 = typename Vec2T<R>::type;
             V2 *dst = reinterpret_cast<V2 *>(q.rec) + ((size_t)sub * q.cap_sub + idx) * 4;
             V2 a, b, c, e;
+#ifdef RTX_EXPERIMENT_ROUND_RAYS
+            o = { R(float(o.x)), R(float(o.y)), R(float(o.z)) };
+            d = { R(float(d.x)), R(float(d.y)), R(float(d.z)) };
+#endif
             a.x = o.x; a.y = o.y;
             b.x = o.z; b.y = d.x;
             c.x = d.y; c.y = d.z;

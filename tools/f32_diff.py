@@ -18,6 +18,11 @@ if name == "random":
 w, cam = scenes.SCENES[name](rta.api, **kw)
 a = rta.render_rows(cam, w, precision=rta.F64)
 b = rta.render_rows(cam, w, precision=rta.F32)
+if os.environ.get("SAVE"):   # keep this library's f64 frame ...
+    np.save(os.environ["SAVE"], a)
+if os.environ.get("REF"):    # ... and compare another library's f64 frame against it
+    b = a
+    a = np.load(os.environ["REF"])
 q = lambda v: np.clip(np.nan_to_num(v * 255.999), 0, 255).astype(np.uint8).astype(int)
 bad = np.abs(q(a) - q(b)).max(axis=2) > 1
 print("%s %dx%d: %.4f%% of pixels differ by more than 1/255 (%d)" % (name, W, H, 100.0 * bad.mean(), bad.sum()))
