@@ -112,6 +112,13 @@ void rtx_context_destroy(rtx_context *ctx);
  * the device memory, at least 8 GiB); frames that could exceed it are rendered in row chunks. */
 int rtx_context_set_workspace_limit(rtx_context *ctx, size_t bytes);
 
+/* Scenes uploaded afterwards test a ray against an object's bounding sphere before the exact
+ * intersection when they hold at least this many bounded objects (spheres, cubes, cylinders with
+ * finite limits); default 16, 0 = always, UINT32_MAX = never.  Results do not depend on it: the
+ * tests only skip objects the reference's intersection routines would miss (no counterpart in
+ * the reference, which tests every object, src/scenes/world.rs:98-107). */
+int rtx_context_set_cull_threshold(rtx_context *ctx, uint32_t min_bounded_objects);
+
 /* Replaces the World a render borrows (src/scenes/world.rs:6-9): validates, repacks and
  * copies the scene to the device.  Fails (as the reference panics, world.rs:123,147) when
  * there are objects but no light. */

@@ -87,6 +87,7 @@ rtx_last_error = _bind("rtx_last_error", C.c_char_p, [])
 rtx_context_create = _bind("rtx_context_create", C.c_int, [C.c_int, C.POINTER(_vp)])
 rtx_context_destroy = _bind("rtx_context_destroy", None, [_vp])
 rtx_context_set_workspace_limit = _bind("rtx_context_set_workspace_limit", C.c_int, [_vp, C.c_size_t])
+rtx_context_set_cull_threshold = _bind("rtx_context_set_cull_threshold", C.c_int, [_vp, C.c_uint32])
 rtx_scene_upload = _bind("rtx_scene_upload", C.c_int, [_vp, C.POINTER(SceneDesc), C.POINTER(_vp)])
 rtx_scene_destroy = _bind("rtx_scene_destroy", None, [_vp])
 rtx_render = _bind("rtx_render", C.c_int, [_vp, _vp, C.POINTER(CameraDesc), C.c_uint32, C.c_int, C.c_uint32, C.c_uint32,
@@ -101,6 +102,7 @@ rtx_device_info = _bind("rtx_device_info", C.c_int, [_vp, C.c_char_p, C.c_size_t
 
 # every symbol include/rtx.h declares
 RTX_SYMBOLS = ["rtx_last_error", "rtx_context_create", "rtx_context_destroy", "rtx_context_set_workspace_limit",
+               "rtx_context_set_cull_threshold",
                "rtx_scene_upload", "rtx_scene_destroy", "rtx_render", "rtx_render_device", "rtx_trace_rays",
                "rtx_probe_rays", "rtx_generate_rays", "rtx_quantize_u8_device", "rtx_device_info"]
 
@@ -216,6 +218,9 @@ class Context:
 
     def set_workspace_limit(self, nbytes):
         _check(rtx_context_set_workspace_limit(self.h, nbytes))
+
+    def set_cull_threshold(self, min_bounded_objects):
+        _check(rtx_context_set_cull_threshold(self.h, min_bounded_objects))
 
     def info(self):
         name = C.create_string_buffer(256)

@@ -30,6 +30,7 @@ namespace rtx {
 template <typename R> struct Num;
 template <> struct Num<double> {
     static constexpr bool exact = true;                      // expression-by-expression restatement
+    static constexpr double cull_slack = 1e-12;              // relative rounding allowance of the bounding-sphere test
     static constexpr double eps = 0.00001;                   // src/utils.rs:1
     static constexpr double big = 1.7976931348623157e308;    // f64::MAX
     static constexpr double inf = __builtin_huge_val();
@@ -46,6 +47,7 @@ template <> struct Num<double> {
 // reciprocal, square root, exp2 and log2, and formulations that stay accurate in 24 bits.
 template <> struct Num<float> {
     static constexpr bool exact = false;
+    static constexpr float cull_slack = 4e-6f;
     static constexpr float eps = 0.00001f;
     static constexpr float big = 3.402823466e38f;
     static constexpr float inf = __builtin_huge_valf();
@@ -276,59 +278,100 @@ template <typename R> RT_DEV R cylinder_c(V3<R> o) { return (o.x * o.x + o.z * o
 template <typename R> RT_DEV R cone_c(V3<R> o) { return (o.x * o.x - o.y * o.y) + o.z * o.z; }
 template <typename R> RT_DEV V3<R> twice(V3<R> o) { return { R(2) * o.x, R(2) * o.y, R(2) * o.z }; }
 
+// ---- bounding-sphere tests ---------------------------------------------------------------
+// In scenes with many objects nearly every ray misses nearly every object, and the exact
+// per-shape test (50-150 instructions, more with its divisions) is spent on proving that.  A
+// test against the object's world-space bounding sphere costs about 20 and needs no transform;
+// when no lane of the wave can hit the object the record is not even fetched.  The spheres are
+// inflated on the host and the comparisons carry a rounding allowance, so a skipped object is
+// one for which the exact test would have found no intersection (in the range that counts):
+// results do not change.
+template <typename R>
+struct CullRay {
+    V3<R> o, d;
+    R d2;    // d . d
+    R dlen;  // |d|
+};
+template <typename R> RT_DEV CullRay<R> cull_ray(V3<R> o, V3<R> d)
+{
+    CullRay<R> c;
+    c.o = o;
+    c.d = d;
+    c.d2 = dot3(d, d);
+    c.dlen = Num<R>::sqrt_(c.d2);
+    return c;
+}
+// LINE: intersections anywhere on the line count (the container bookkeeping of refraction reads
+// those behind the origin too).  Otherwise only 0 <= t <= t_max counts.
+template <typename R, bool LINE>
+RT_DEV bool may_hit(const BoundRec<R> &b, const CullRay<R> &cr, R t_max)
+{
+    const V3<R> m = { b.c[0] - cr.o.x, b.c[1] - cr.o.y, b.c[2] - cr.o.z };
+    const R tc = dot3(m, cr.d);
+    const R m2 = dot3(m, m);
+    const R r2 = b.r * b.r;
+    const R md = m2 * cr.d2;
+    // d2 * (squared distance of the centre from the line) against d2 * r^2; r = inf never skips
+    if ((md - tc * tc) - r2 * cr.d2 > Num<R>::cull_slack * md) return false;
+    if constexpr (!LINE) {
+        if (tc < R(0) && m2 > r2) return false;  // the whole sphere lies behind the origin
+        // the ray enters the sphere no earlier than (tc - r |d|) / d2
+        if ((tc - b.r * cr.dlen) - Num<R>::cull_slack * Num<R>::abs_(tc) > t_max * cr.d2) return false;
+    }
+    return true;
+}
+
 // ---- walking the object tables ---------------------------------------------------------
 // Visit records 0..n-1 of one table with a wave-uniform index.  The table is read through a
 // constant-address-space pointer: that is what makes the compiler fetch each record once per
 // wave through the scalar cache into SGPRs even inside loops that also store to memory (with a
 // generic pointer it falls back to one vector load per lane there).  The tables are written
 // before the launch and never by a kernel that walks them.  The other waves of the SIMD cover
-// the fetch latency.
+// the fetch latency.  keep(slot) says whether this lane's ray can hit the object at all; the
+// record is fetched only when some lane's can.
 #define RT_CONSTANT_AS __attribute__((address_space(4)))
-template <typename Rec, typename Body>
-RT_DEV void walk_table(const Rec *recs, uint32_t n, uint32_t slot0, Body &&body)
+template <typename Rec> RT_DEV Rec load_uniform(const Rec *p)
 {
-    const RT_CONSTANT_AS Rec *table = (const RT_CONSTANT_AS Rec *)recs;
-#if RTX_WALK_PREFETCH
-    if (n == 0) return;
-    Rec cur;
-    __builtin_memcpy(&cur, table, sizeof(Rec));
-    for (uint32_t i = 0; i < n; ++i) {
-        Rec nxt;
-        __builtin_memcpy(&nxt, table + ((i + 1 < n) ? i + 1 : i), sizeof(Rec));
-        body(cur, slot0 + i);
-        cur = nxt;
-    }
-#else
-    for (uint32_t i = 0; i < n; ++i) {
-        Rec rec;
-        __builtin_memcpy(&rec, table + i, sizeof(Rec));
-        body(rec, slot0 + i);
-    }
-#endif
+    Rec rec;
+    __builtin_memcpy(&rec, (const RT_CONSTANT_AS Rec *)p, sizeof(Rec));
+    return rec;
 }
+template <typename Rec, typename Keep, typename Body>
+RT_DEV void walk_table(const Rec *recs, uint32_t n, uint32_t slot0, Keep &&keep, Body &&body)
+{
+    for (uint32_t i = 0; i < n; ++i) {
+        const bool k = keep(slot0 + i);
+        if (__ballot(k) == 0ull) continue;
+        const Rec rec = load_uniform(recs + i);
+        if (k) body(rec, slot0 + i);
+    }
+}
+struct KeepAll {
+    RT_DEV bool operator()(uint32_t) const { return true; }
+};
 
 // Object::intersect for every object of the world (src/shapes/objects.rs:185-198 with
 // src/rays.rs:30-34): the ray goes into object space (direction not renormalised), then the
 // per-shape routine runs.  For each object `per(slot, run)` is called once; `run(emit)`
 // performs the intersection and calls emit(t) per intersection.
-template <typename R, typename Per>
-RT_DEV void walk_scene(const SceneDev<R> &S, V3<R> ro, V3<R> rd, Per &&per)
+template <typename R, typename Keep, typename Per>
+RT_DEV void walk_scene(const SceneDev<R> &S, V3<R> ro, V3<R> rd, Keep &&keep, Per &&per)
 {
     uint32_t slot0 = 0;
-    walk_table(S.sph, S.n_sph, slot0, [&](const XformRec<R> &rec, uint32_t slot) {
+    walk_table(S.sph, S.n_sph, slot0, keep, [&](const XformRec<R> &rec, uint32_t slot) {
         const V3<R> o = xform_point(rec.m, ro);
         const V3<R> d = xform_vector(rec.m, rd);
         per(slot, [&](auto &&emit) { isect_sphere(o, d, sphere_c(o), emit); });
     });
     slot0 += S.n_sph;
-    walk_table(S.pln, S.n_pln, slot0, [&](const PlaneRec<R> &rec, uint32_t slot) {
+    walk_table(S.pln, S.n_pln, slot0, KeepAll(), [&](const PlaneRec<R> &rec, uint32_t slot) {
         // only the y row of the object-space ray is read by planes.rs:11-17
         const R oy = ((rec.m[0] * ro.x + rec.m[1] * ro.y) + rec.m[2] * ro.z) + rec.m[3];
         const R dy = (rec.m[0] * rd.x + rec.m[1] * rd.y) + rec.m[2] * rd.z;
         per(slot, [&](auto &&emit) { isect_plane(-oy, dy, emit); });
     });
     slot0 += S.n_pln;
-    walk_table(S.cub, S.n_cub, slot0, [&](const XformRec<R> &rec, uint32_t slot) {
+    walk_table(S.cub, S.n_cub, slot0, keep, [&](const XformRec<R> &rec, uint32_t slot) {
         const V3<R> o = xform_point(rec.m, ro);
         const V3<R> d = xform_vector(rec.m, rd);
         const V3<R> lo = { R(-1) - o.x, R(-1) - o.y, R(-1) - o.z };
@@ -336,13 +379,13 @@ RT_DEV void walk_scene(const SceneDev<R> &S, V3<R> ro, V3<R> rd, Per &&per)
         per(slot, [&](auto &&emit) { isect_cube(lo, hi, d, emit); });
     });
     slot0 += S.n_cub;
-    walk_table(S.cyl, S.n_cyl, slot0, [&](const CappedRec<R> &rec, uint32_t slot) {
+    walk_table(S.cyl, S.n_cyl, slot0, keep, [&](const CappedRec<R> &rec, uint32_t slot) {
         const V3<R> o = xform_point(rec.m, ro);
         const V3<R> d = xform_vector(rec.m, rd);
         per(slot, [&](auto &&emit) { isect_cylinder(o, twice(o), cylinder_c(o), d, rec.ymin, rec.ymax, rec.closed != 0, emit); });
     });
     slot0 += S.n_cyl;
-    walk_table(S.con, S.n_con, slot0, [&](const CappedRec<R> &rec, uint32_t slot) {
+    walk_table(S.con, S.n_con, slot0, keep, [&](const CappedRec<R> &rec, uint32_t slot) {
         const V3<R> o = xform_point(rec.m, ro);
         const V3<R> d = xform_vector(rec.m, rd);
         per(slot, [&](auto &&emit) { isect_cone(o, twice(o), cone_c(o), d, rec.ymin, rec.ymax, rec.closed != 0, emit); });
@@ -358,36 +401,36 @@ template <typename R> RT_DEV V3<R> xform_vector9(const R *m, V3<R> v)
              (m[3] * v.x + m[4] * v.y) + m[5] * v.z,
              (m[6] * v.x + m[7] * v.y) + m[8] * v.z };
 }
-template <typename R, typename Per>
-RT_DEV void walk_scene_primary(const PrimScene<R> &P, V3<R> rd, Per &&per)
+template <typename R, typename Keep, typename Per>
+RT_DEV void walk_scene_primary(const PrimScene<R> &P, V3<R> rd, Keep &&keep, Per &&per)
 {
     uint32_t slot0 = 0;
-    walk_table(P.sph, P.n_sph, slot0, [&](const PrimSphereRec<R> &rec, uint32_t slot) {
+    walk_table(P.sph, P.n_sph, slot0, keep, [&](const PrimSphereRec<R> &rec, uint32_t slot) {
         const V3<R> o = { rec.o[0], rec.o[1], rec.o[2] };
         const V3<R> d = xform_vector9(rec.m, rd);
         per(slot, [&](auto &&emit) { isect_sphere(o, d, rec.c, emit); });
     });
     slot0 += P.n_sph;
-    walk_table(P.pln, P.n_pln, slot0, [&](const PrimPlaneRec<R> &rec, uint32_t slot) {
+    walk_table(P.pln, P.n_pln, slot0, KeepAll(), [&](const PrimPlaneRec<R> &rec, uint32_t slot) {
         const R dy = (rec.m[0] * rd.x + rec.m[1] * rd.y) + rec.m[2] * rd.z;
         per(slot, [&](auto &&emit) { isect_plane(rec.neg_oy, dy, emit); });
     });
     slot0 += P.n_pln;
-    walk_table(P.cub, P.n_cub, slot0, [&](const PrimCubeRec<R> &rec, uint32_t slot) {
+    walk_table(P.cub, P.n_cub, slot0, keep, [&](const PrimCubeRec<R> &rec, uint32_t slot) {
         const V3<R> d = xform_vector9(rec.m, rd);
         const V3<R> lo = { rec.lo[0], rec.lo[1], rec.lo[2] };
         const V3<R> hi = { rec.hi[0], rec.hi[1], rec.hi[2] };
         per(slot, [&](auto &&emit) { isect_cube(lo, hi, d, emit); });
     });
     slot0 += P.n_cub;
-    walk_table(P.cyl, P.n_cyl, slot0, [&](const PrimCappedRec<R> &rec, uint32_t slot) {
+    walk_table(P.cyl, P.n_cyl, slot0, keep, [&](const PrimCappedRec<R> &rec, uint32_t slot) {
         const V3<R> o = { rec.o[0], rec.o[1], rec.o[2] };
         const V3<R> o2 = { rec.o2[0], rec.o2[1], rec.o2[2] };
         const V3<R> d = xform_vector9(rec.m, rd);
         per(slot, [&](auto &&emit) { isect_cylinder(o, o2, rec.c, d, rec.ymin, rec.ymax, rec.closed != 0, emit); });
     });
     slot0 += P.n_cyl;
-    walk_table(P.con, P.n_con, slot0, [&](const PrimCappedRec<R> &rec, uint32_t slot) {
+    walk_table(P.con, P.n_con, slot0, keep, [&](const PrimCappedRec<R> &rec, uint32_t slot) {
         const V3<R> o = { rec.o[0], rec.o[1], rec.o[2] };
         const V3<R> o2 = { rec.o2[0], rec.o2[1], rec.o2[2] };
         const V3<R> d = xform_vector9(rec.m, rd);
@@ -488,7 +531,7 @@ RT_DEV Hit<R> closest_hit_with(const SceneDev<R> &S, Walk &&walk)
     h.top1_t = h.top2_t = -Num<R>::inf;
     // true when `slot` precedes `other` in World.objects
     auto before = [&](uint32_t slot, uint32_t other) { return S.slot_obj[slot] < S.slot_obj[other]; };
-    walk([&](uint32_t slot, auto &&run) {
+    walk(&h.t, [&](uint32_t slot, auto &&run) {
         if constexpr (!TRACK) {
             run([&](R t) {
                 if (t >= R(0) && t <= h.t) {
@@ -525,15 +568,33 @@ RT_DEV Hit<R> closest_hit_with(const SceneDev<R> &S, Walk &&walk)
     if (h.slot != kNone) h.obj = S.slot_obj[h.slot];
     return h;
 }
-template <typename R, bool TRACK>
-RT_DEV Hit<R> closest_hit(const SceneDev<R> &S, V3<R> ro, V3<R> rd)
+// The closest-hit walks.  t_limit: hits beyond it need not be found (inf for color_at; the
+// distance to the light for a shadow ray, which only asks whether the closest hit lies before it).
+template <typename R, bool TRACK, bool CULL>
+RT_DEV Hit<R> closest_hit(const SceneDev<R> &S, V3<R> ro, V3<R> rd, R t_limit)
 {
-    return closest_hit_with<R, TRACK>(S, [&](auto &&per) { walk_scene(S, ro, rd, per); });
+    if constexpr (CULL) {
+        const CullRay<R> cr = cull_ray(ro, rd);
+        return closest_hit_with<R, TRACK>(S, [&](const R *best, auto &&per) {
+            walk_scene(S, ro, rd,
+                       [&](uint32_t slot) { return may_hit<R, TRACK>(load_uniform(S.bnd + slot), cr, Num<R>::min_(*best, t_limit)); },
+                       per);
+        });
+    } else {
+        return closest_hit_with<R, TRACK>(S, [&](const R *, auto &&per) { walk_scene(S, ro, rd, KeepAll(), per); });
+    }
 }
-template <typename R, bool TRACK>
-RT_DEV Hit<R> closest_hit_primary(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> rd)
+template <typename R, bool TRACK, bool CULL>
+RT_DEV Hit<R> closest_hit_primary(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> ro, V3<R> rd)
 {
-    return closest_hit_with<R, TRACK>(S, [&](auto &&per) { walk_scene_primary(P, rd, per); });
+    if constexpr (CULL) {
+        const CullRay<R> cr = cull_ray(ro, rd);
+        return closest_hit_with<R, TRACK>(S, [&](const R *best, auto &&per) {
+            walk_scene_primary(P, rd, [&](uint32_t slot) { return may_hit<R, TRACK>(load_uniform(S.bnd + slot), cr, *best); }, per);
+        });
+    } else {
+        return closest_hit_with<R, TRACK>(S, [&](const R *, auto &&per) { walk_scene_primary(P, rd, KeepAll(), per); });
+    }
 }
 
 // src/scenes/world.rs:146-158.  shadowed iff the closest hit (t >= 0) lies before the light
@@ -542,16 +603,23 @@ RT_DEV Hit<R> closest_hit_primary(const SceneDev<R> &S, const PrimScene<R> &P, V
 template <typename R, uint32_t SF>
 RT_DEV bool is_shadowed(const SceneDev<R> &S, V3<R> p, V3<R> dir, R distance)
 {
+    constexpr bool CULL = (SF & SF_CULL) != 0;
     if constexpr ((SF & SF_ALL_CAST) != 0) {
         bool shadowed = false;
-        walk_scene(S, p, dir, [&](uint32_t, auto &&run) {
+        auto per = [&](uint32_t, auto &&run) {
             run([&](R t) {
                 if (t >= R(0) && t < distance) shadowed = true;
             });
-        });
+        };
+        if constexpr (CULL) {
+            const CullRay<R> cr = cull_ray(p, dir);
+            walk_scene(S, p, dir, [&](uint32_t slot) { return !shadowed && may_hit<R, false>(load_uniform(S.bnd + slot), cr, distance); }, per);
+        } else {
+            walk_scene(S, p, dir, KeepAll(), per);
+        }
         return shadowed;
     } else {
-        Hit<R> h = closest_hit<R, false>(S, p, dir);
+        Hit<R> h = closest_hit<R, false, CULL>(S, p, dir, distance);
         if (h.slot == kNone) return false;
         return h.t < distance && (S.cold[h.obj].flags & OF_CASTS_SHADOW) != 0;
     }
@@ -641,8 +709,9 @@ RT_DEV Node<R> trace_node(const SceneDev<R> &S, const PrimScene<R> *P, V3<R> ro,
     nd.has_reflect = nd.has_refract = false;
     nd.lighting = { R(0), R(0), R(0) };
     Hit<R> h;
-    if constexpr (PRIMARY) h = closest_hit_primary<R, TRACK>(S, *P, rd);
-    else h = closest_hit<R, TRACK>(S, ro, rd);
+    constexpr bool CULL = (SF & SF_CULL) != 0;
+    if constexpr (PRIMARY) h = closest_hit_primary<R, TRACK, CULL>(S, *P, ro, rd);
+    else h = closest_hit<R, TRACK, CULL>(S, ro, rd, Num<R>::inf);
     nd.hit = h.slot != kNone;
     nd.obj = h.obj;
     nd.t = h.t;

@@ -236,16 +236,26 @@ __global__ void __launch_bounds__(kBlock) k_quantize(const R *__restrict__ rgb, 
 }
 
 // ---- launchers --------------------------------------------------------------------------
-#define RTX_SF_SWITCH(sf, CALL)                                                            \
-    switch ((sf) & 7u) {                                                                   \
-    case 0u: CALL(0u); break;                                                              \
-    case 1u: CALL(1u); break;                                                              \
-    case 2u: CALL(2u); break;                                                              \
-    case 3u: CALL(3u); break;                                                              \
-    case 4u: CALL(4u); break;                                                              \
-    case 5u: CALL(5u); break;                                                              \
-    case 6u: CALL(6u); break;                                                              \
-    default: CALL(7u); break;                                                              \
+// One instantiation per combination of the feature bits that change code.
+constexpr uint32_t sf_variant(uint32_t k) { return (k & 7u) | ((k & 8u) ? SF_CULL : 0u); }
+#define RTX_SF_SWITCH(sf, CALL)                                                \
+    switch (((sf) & 7u) | (((sf) & SF_CULL) ? 8u : 0u)) {                      \
+    case 0u: CALL(sf_variant(0u)); break;                                      \
+    case 1u: CALL(sf_variant(1u)); break;                                      \
+    case 2u: CALL(sf_variant(2u)); break;                                      \
+    case 3u: CALL(sf_variant(3u)); break;                                      \
+    case 4u: CALL(sf_variant(4u)); break;                                      \
+    case 5u: CALL(sf_variant(5u)); break;                                      \
+    case 6u: CALL(sf_variant(6u)); break;                                      \
+    case 7u: CALL(sf_variant(7u)); break;                                      \
+    case 8u: CALL(sf_variant(8u)); break;                                      \
+    case 9u: CALL(sf_variant(9u)); break;                                      \
+    case 10u: CALL(sf_variant(10u)); break;                                    \
+    case 11u: CALL(sf_variant(11u)); break;                                    \
+    case 12u: CALL(sf_variant(12u)); break;                                    \
+    case 13u: CALL(sf_variant(13u)); break;                                    \
+    case 14u: CALL(sf_variant(14u)); break;                                    \
+    default: CALL(sf_variant(15u)); break;                                     \
     }
 
 template <typename R>

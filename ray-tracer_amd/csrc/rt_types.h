@@ -18,6 +18,7 @@ enum : uint32_t {
     SF_TRANSPARENT = 2u,  // some object has transparency != 0
     SF_ALL_CAST = 4u,     // every object casts a shadow: shadow rays may stop at any hit
     SF_PATTERN = 8u,      // some object carries a non-solid pattern
+    SF_CULL = 16u,        // enough bounded objects that testing their bounding spheres first pays
 };
 
 // ---- intersection tables -------------------------------------------------------------
@@ -43,6 +44,15 @@ struct alignas(sizeof(R) * 4) CappedRec {
     R ymin, ymax;
     uint32_t closed;
     uint32_t pad[(2 * sizeof(R) - 4) / 4];
+};
+
+// Bounding sphere of one object in world space, by slot.  r = +inf for planes, cones and
+// cylinders without finite y limits; finite radii are inflated on the host so that a line
+// that misses the sphere cannot produce an intersection in the exact test either.
+template <typename R>
+struct alignas(sizeof(R) * 4) BoundRec {
+    R c[3];
+    R r;
 };
 
 // ---- primary-ray tables -----------------------------------------------------------------
@@ -113,12 +123,13 @@ struct SceneDev {
     const XformRec<R> *cub;
     const CappedRec<R> *cyl;
     const CappedRec<R> *con;
+    const BoundRec<R> *bnd;    // by slot
     const uint32_t *slot_obj;  // slot -> index in World.objects (the tie-break order among equal t)
     const ColdRec<R> *cold;    // by index in World.objects
     uint32_t n_sph, n_pln, n_cub, n_cyl, n_con;
     uint32_t n;
     uint32_t flags;
-    uint32_t pad;
+    uint32_t n_bounded;        // objects with a finite bounding sphere (0: the walks skip the tests)
     R light_pos[3];
     R light_int[3];
 };

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <limits>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -77,6 +78,7 @@ struct rtx_context {
     int clock_mhz = 0;
     std::string name;
     size_t workspace_limit = (size_t)8 << 30;
+    uint32_t cull_min_objects = 16;  // scenes with at least this many bounded objects get the bounding-sphere tests
     uint32_t blocks_per_cu = 8;
     std::mutex mu;
     std::vector<std::unique_ptr<Slot>> slots;
@@ -158,9 +160,53 @@ struct Tables {
     std::vector<XformRec<R>> sph, cub;
     std::vector<PlaneRec<R>> pln;
     std::vector<CappedRec<R>> cyl, con;
+    std::vector<BoundRec<R>> bnd;
     std::vector<uint32_t> slot_obj;
     std::vector<ColdRec<R>> cold;
+    uint32_t n_bounded = 0;
 };
+
+// World-space bounding sphere of object i.  The object-space shape is bounded by a sphere
+// about (0, y_mid, 0); the object's transform is the inverse of the cached inverse (affine:
+// x -> A x + b), so the world centre is A^-1 ((0, y_mid, 0) - b) and lengths grow by at most the
+// Frobenius norm of A^-1.  Returns r = +inf when the shape is unbounded or A is not invertible
+// in double precision.
+void bounding_sphere(const rtx_scene_desc *d, uint32_t i, double c[3], double *r)
+{
+    const double inf = std::numeric_limits<double>::infinity();
+    c[0] = c[1] = c[2] = 0.0;
+    *r = inf;
+    double ymid = 0.0, r_obj;
+    const double lo = d->ymin[i], hi = d->ymax[i];
+    switch (d->shape_type[i]) {
+    case RTX_SPHERE: r_obj = 1.0; break;
+    case RTX_CUBE: r_obj = std::sqrt(3.0); break;
+    case RTX_CYLINDER:
+        if (!std::isfinite(lo) || !std::isfinite(hi)) return;
+        ymid = 0.5 * (lo + hi);
+        r_obj = std::sqrt(1.0 + 0.25 * (hi - lo) * (hi - lo));
+        break;
+    // A cone is never bounded: when the ray is parallel to one of its halves the reference
+    // keeps the single root -c/(2b) without clipping it to [min, max] (src/shapes/cones.rs:44-52),
+    // and its caps accept x^2 + z^2 <= |y| rather than y^2 (cones.rs:103).
+    default: return;  // plane, cone
+    }
+    const double *m = d->inverse + (size_t)i * 16;
+    const double a00 = m[0], a01 = m[1], a02 = m[2], a10 = m[4], a11 = m[5], a12 = m[6], a20 = m[8], a21 = m[9], a22 = m[10];
+    const double det = a00 * (a11 * a22 - a12 * a21) - a01 * (a10 * a22 - a12 * a20) + a02 * (a10 * a21 - a11 * a20);
+    if (!std::isfinite(det) || std::fabs(det) < 1e-300) return;
+    const double inv[9] = { (a11 * a22 - a12 * a21) / det, (a02 * a21 - a01 * a22) / det, (a01 * a12 - a02 * a11) / det,
+                            (a12 * a20 - a10 * a22) / det, (a00 * a22 - a02 * a20) / det, (a02 * a10 - a00 * a12) / det,
+                            (a10 * a21 - a11 * a20) / det, (a01 * a20 - a00 * a21) / det, (a00 * a11 - a01 * a10) / det };
+    const double v[3] = { 0.0 - m[3], ymid - m[7], 0.0 - m[11] };
+    double frob = 0.0;
+    for (int k = 0; k < 9; ++k) frob += inv[k] * inv[k];
+    frob = std::sqrt(frob);
+    for (int r3 = 0; r3 < 3; ++r3) c[r3] = inv[r3 * 3] * v[0] + inv[r3 * 3 + 1] * v[1] + inv[r3 * 3 + 2] * v[2];
+    const double rad = r_obj * frob;
+    if (!std::isfinite(rad) || !std::isfinite(c[0]) || !std::isfinite(c[1]) || !std::isfinite(c[2])) return;
+    *r = rad;
+}
 
 template <typename R>
 void fill_tables(const rtx_scene_desc *d, const std::vector<uint8_t> &container, Tables<R> &t)
@@ -202,6 +248,20 @@ void fill_tables(const rtx_scene_desc *d, const std::vector<uint8_t> &container,
             if (d->shape_type[i] != shape) continue;
             const double *inv = d->inverse + (size_t)i * 16;
             t.slot_obj.push_back(i);
+            {
+                double c[3], r;
+                bounding_sphere(d, i, c, &r);
+                BoundRec<R> b;
+                // inflation: covers the rounding of the test itself and of the centre
+                // inflation: a relative part for the rounding of the test, an absolute part for the
+                // rounding of the centre to R
+                const double rel = sizeof(R) == 8 ? 1e-6 : 1e-3, ulp = sizeof(R) == 8 ? 1e-14 : 1e-6;
+                const double cmax = std::max(std::fabs(c[0]), std::max(std::fabs(c[1]), std::fabs(c[2])));
+                for (int k = 0; k < 3; ++k) b.c[k] = (R)c[k];
+                b.r = std::isfinite(r) ? (R)(r * (1.0 + rel) + cmax * ulp) : (R)r;
+                if (std::isfinite((double)b.r)) t.n_bounded++;
+                t.bnd.push_back(b);
+            }
             if (shape == RTX_SPHERE || shape == RTX_CUBE) {
                 XformRec<R> r;
                 for (int k = 0; k < 12; ++k) r.m[k] = (R)inv[k];
@@ -230,8 +290,8 @@ int upload_tables(const Tables<R> &t, uint32_t sf, const rtx_scene_desc *d, void
     const size_t b_sph = pad(t.sph.size() * sizeof(XformRec<R>)), b_pln = pad(t.pln.size() * sizeof(PlaneRec<R>)),
                  b_cub = pad(t.cub.size() * sizeof(XformRec<R>)), b_cyl = pad(t.cyl.size() * sizeof(CappedRec<R>)),
                  b_con = pad(t.con.size() * sizeof(CappedRec<R>)), b_slot = pad(t.slot_obj.size() * sizeof(uint32_t)),
-                 b_cold = pad(t.cold.size() * sizeof(ColdRec<R>));
-    const size_t total = b_sph + b_pln + b_cub + b_cyl + b_con + b_slot + b_cold + 256;
+                 b_cold = pad(t.cold.size() * sizeof(ColdRec<R>)), b_bnd = pad(t.bnd.size() * sizeof(BoundRec<R>));
+    const size_t total = b_sph + b_pln + b_cub + b_cyl + b_con + b_slot + b_cold + b_bnd + 256;
     std::vector<char> host(total, 0);
     size_t off = 0;
     auto put = [&](const void *src, size_t bytes, size_t padded) {
@@ -247,6 +307,7 @@ int upload_tables(const Tables<R> &t, uint32_t sf, const rtx_scene_desc *d, void
     const size_t o_con = put(t.con.data(), t.con.size() * sizeof(CappedRec<R>), b_con);
     const size_t o_slot = put(t.slot_obj.data(), t.slot_obj.size() * sizeof(uint32_t), b_slot);
     const size_t o_cold = put(t.cold.data(), t.cold.size() * sizeof(ColdRec<R>), b_cold);
+    const size_t o_bnd = put(t.bnd.data(), t.bnd.size() * sizeof(BoundRec<R>), b_bnd);
     HIP_TRY(hipMalloc(blob, total));
     HIP_TRY(hipMemcpy(*blob, host.data(), total, hipMemcpyHostToDevice));
     char *base = (char *)*blob;
@@ -258,6 +319,8 @@ int upload_tables(const Tables<R> &t, uint32_t sf, const rtx_scene_desc *d, void
     dev->con = (const CappedRec<R> *)(base + o_con);
     dev->slot_obj = (const uint32_t *)(base + o_slot);
     dev->cold = (const ColdRec<R> *)(base + o_cold);
+    dev->bnd = (const BoundRec<R> *)(base + o_bnd);
+    dev->n_bounded = t.n_bounded;
     dev->n_sph = (uint32_t)t.sph.size();
     dev->n_pln = (uint32_t)t.pln.size();
     dev->n_cub = (uint32_t)t.cub.size();
@@ -641,6 +704,10 @@ int rtx_context_create(int device_id, rtx_context **out)
     // memory (48 GB of 288) lets such a frame run as one chunk and leaves room for several
     // concurrent render calls.
     ctx->workspace_limit = std::max<size_t>((size_t)8 << 30, prop.totalGlobalMem / 6);
+    if (const char *e = std::getenv("RTX_CULL_MIN_OBJECTS")) {
+        int v = std::atoi(e);
+        if (v >= 0) ctx->cull_min_objects = (uint32_t)v;
+    }
     if (const char *e = std::getenv("RTX_BLOCKS_PER_CU")) {
         int v = std::atoi(e);
         if (v >= 1 && v <= 64) ctx->blocks_per_cu = (uint32_t)v;
@@ -677,6 +744,14 @@ int rtx_context_set_workspace_limit(rtx_context *ctx, size_t bytes)
     if (bytes < ((size_t)1 << 20)) return fail(RTX_ERR_INVALID, "workspace limit below 1 MiB");
     std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->workspace_limit = bytes;
+    return RTX_OK;
+}
+
+int rtx_context_set_cull_threshold(rtx_context *ctx, uint32_t min_bounded_objects)
+{
+    if (!ctx) return fail(RTX_ERR_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->cull_min_objects = min_bounded_objects;
     return RTX_OK;
 }
 
@@ -732,11 +807,14 @@ int rtx_scene_upload(rtx_context *ctx, const rtx_scene_desc *d, rtx_scene **out)
     std::unique_ptr<rtx_scene> s(new rtx_scene);
     s->ctx = ctx;
     s->n = n;
-    s->sf = sf;
     Tables<double> t64;
     Tables<float> t32;
     fill_tables<double>(d, container, t64);
     fill_tables<float>(d, container, t32);
+    // Bounding-sphere tests cost about 20 instructions per object and ray: they pay once most
+    // rays miss most objects, which a handful of large objects in view does not give.
+    if (t64.n_bounded >= ctx->cull_min_objects) sf |= SF_CULL;
+    s->sf = sf;
     int rc = upload_tables<double>(t64, sf, d, &s->blob64, &s->dev64);
     if (!rc) rc = upload_tables<float>(t32, sf, d, &s->blob32, &s->dev32);
     if (rc) {

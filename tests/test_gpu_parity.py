@@ -278,6 +278,39 @@ def test_row_tiles_and_chunks_agree(orc, rta):
     ctx.close()
 
 
+def test_bounding_sphere_tests_change_nothing(orc, rta):
+    """Ray counters and colours do not depend on whether objects are skipped by their bounding
+    spheres (threshold 0 = always test, 2^32-1 = never).  Colours are compared to 1e-12: the
+    terms of a pixel's sum are added atomically, in an order that varies from run to run."""
+    from ray_tracer_amd import scenes
+    cases = [(scenes.glass_scene, dict(hsize=96, vsize=54)), (scenes.random_scene, dict(n_objects=200, hsize=96, vsize=54))]
+    cases += [(shapes_scene, dict(kind=k)) for k in range(4)]
+    cases += [(unit_shapes_scene, dict(shape=s)) for s in range(7)]
+    frames = {}
+    for threshold in (0, 0xffffffff):
+        ctx = rta.Context()
+        ctx.set_cull_threshold(threshold)
+        for i, (fn, kw) in enumerate(cases):
+            w, cam = fn(rta.api, **kw)
+            scene = rta.Scene(ctx, rta.flatten(w))
+            cd = rta.camera_desc(cam)
+            out = np.empty((cd.vsize, cd.hsize, 3))
+            st = rta.Stats()
+            rta._check(rta.rtx_render(ctx.h, scene.h, cd, 5, rta.F64, 0, cd.vsize, out.ctypes.data, out.nbytes, None, None, st))
+            rays = np.ascontiguousarray(axis_rays())
+            cols = np.empty((len(rays), 3))
+            rta._check(rta.rtx_trace_rays(ctx.h, scene.h, rays.ctypes.data_as(rta._dp), len(rays), 5, rta.F64,
+                                          cols.ctypes.data_as(rta._dp), None))
+            frames[(threshold, i)] = (out, st.color_rays, st.shadow_rays, cols)
+            scene.close()
+        ctx.close()
+    for i in range(len(cases)):
+        a, b = frames[(0, i)], frames[(0xffffffff, i)]
+        assert a[1:3] == b[1:3], "case %d" % i
+        assert np.allclose(a[0], b[0], rtol=0.0, atol=1e-12, equal_nan=True), "case %d" % i
+        assert np.allclose(a[3], b[3], rtol=0.0, atol=1e-12, equal_nan=True), "case %d" % i
+
+
 def test_f32_fast_path(orc, rta):
     """f32 colours within 1/255 after 8-bit quantisation (src/scenes/canvas.rs:84-86) on at
     least 99.9 % of the pixels, against the f64 oracle."""
