@@ -54,6 +54,10 @@ struct alignas(sizeof(R) * 4) BoundRec {
     R c[3];
     R r;
 };
+// When the bounding-sphere tests are on, the slots of a shape table are ordered along a
+// space-filling curve and every kCluster consecutive slots share one more bounding sphere, so
+// a ray tests n / kCluster cluster spheres and then only the members of the clusters it meets.
+constexpr uint32_t kCluster = 32;
 
 // ---- primary-ray tables -----------------------------------------------------------------
 // Every primary ray starts at the camera, so each object's object-space ray origin and the
@@ -124,12 +128,15 @@ struct SceneDev {
     const CappedRec<R> *cyl;
     const CappedRec<R> *con;
     const BoundRec<R> *bnd;    // by slot
+    const BoundRec<R> *cl;     // cluster spheres; those of shape s start at cl_off[s]
+    uint32_t cl_off[5];
+    uint32_t pad;
     const uint32_t *slot_obj;  // slot -> index in World.objects (the tie-break order among equal t)
     const ColdRec<R> *cold;    // by index in World.objects
     uint32_t n_sph, n_pln, n_cub, n_cyl, n_con;
     uint32_t n;
     uint32_t flags;
-    uint32_t n_bounded;        // objects with a finite bounding sphere (0: the walks skip the tests)
+    uint32_t pad2;
     R light_pos[3];
     R light_int[3];
 };

@@ -160,31 +160,120 @@ struct Tables {
     std::vector<XformRec<R>> sph, cub;
     std::vector<PlaneRec<R>> pln;
     std::vector<CappedRec<R>> cyl, con;
-    std::vector<BoundRec<R>> bnd;
+    std::vector<BoundRec<R>> bnd, cl;
+    uint32_t cl_off[5] = { 0, 0, 0, 0, 0 };
     std::vector<uint32_t> slot_obj;
     std::vector<ColdRec<R>> cold;
-    uint32_t n_bounded = 0;
 };
 
-// World-space bounding sphere of object i.  The object-space shape is bounded by a sphere
-// about (0, y_mid, 0); the object's transform is the inverse of the cached inverse (affine:
-// x -> A x + b), so the world centre is A^-1 ((0, y_mid, 0) - b) and lengths grow by at most the
-// Frobenius norm of A^-1.  Returns r = +inf when the shape is unbounded or A is not invertible
-// in double precision.
+struct Bound {
+    double c[3], r;
+};
+
+void bounding_sphere(const rtx_scene_desc *d, uint32_t i, double c[3], double *r);
+
+std::vector<Bound> scene_bounds(const rtx_scene_desc *d, uint32_t *n_bounded)
+{
+    std::vector<Bound> b(d->n_objects);
+    *n_bounded = 0;
+    for (uint32_t i = 0; i < d->n_objects; ++i) {
+        bounding_sphere(d, i, b[i].c, &b[i].r);
+        if (std::isfinite(b[i].r)) ++*n_bounded;
+    }
+    return b;
+}
+
+// Order of the objects of one shape inside its table.  Without the bounding-sphere tests it is
+// the World's order.  With them, bounded objects come first, sorted along a Morton curve through
+// their centres so that consecutive slots are neighbours in space; unbounded ones follow.  The
+// order inside a table is free: ties between equal t are settled by World index, not by slot.
+std::vector<uint32_t> table_order(const rtx_scene_desc *d, const std::vector<Bound> &bounds, uint32_t shape, bool cull)
+{
+    std::vector<uint32_t> idx;
+    for (uint32_t i = 0; i < d->n_objects; ++i)
+        if (d->shape_type[i] == shape) idx.push_back(i);
+    if (!cull || idx.empty()) return idx;
+    double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
+    for (uint32_t i : idx)
+        if (std::isfinite(bounds[i].r))
+            for (int k = 0; k < 3; ++k) {
+                lo[k] = std::min(lo[k], bounds[i].c[k]);
+                hi[k] = std::max(hi[k], bounds[i].c[k]);
+            }
+    auto spread = [](uint64_t v) {  // 21 bits -> every third bit
+        v &= 0x1fffffull;
+        v = (v | v << 32) & 0x1f00000000ffffull;
+        v = (v | v << 16) & 0x1f0000ff0000ffull;
+        v = (v | v << 8) & 0x100f00f00f00f00full;
+        v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+        v = (v | v << 2) & 0x1249249249249249ull;
+        return v;
+    };
+    std::vector<std::pair<uint64_t, uint32_t>> keyed;
+    for (uint32_t i : idx) {
+        uint64_t key = ~0ull;  // unbounded objects last
+        if (std::isfinite(bounds[i].r)) {
+            key = 0;
+            for (int k = 0; k < 3; ++k) {
+                const double span = hi[k] - lo[k];
+                const double u = span > 0.0 ? (bounds[i].c[k] - lo[k]) / span : 0.0;
+                key |= spread((uint64_t)(std::min(std::max(u, 0.0), 1.0) * 2097151.0)) << k;
+            }
+        }
+        keyed.emplace_back(key, i);
+    }
+    std::stable_sort(keyed.begin(), keyed.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+    for (size_t k = 0; k < keyed.size(); ++k) idx[k] = keyed[k].second;
+    return idx;
+}
+
+// Largest singular value of a 3x3 matrix (row-major): square root of the largest eigenvalue of
+// A^T A, by the trigonometric solution of the symmetric 3x3 eigenproblem.
+double largest_singular_value(const double a[9])
+{
+    double b[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) b[i][j] = a[i] * a[j] + a[3 + i] * a[3 + j] + a[6 + i] * a[6 + j];
+    const double p1 = b[0][1] * b[0][1] + b[0][2] * b[0][2] + b[1][2] * b[1][2];
+    double top;
+    if (p1 == 0.0) {
+        top = std::max(b[0][0], std::max(b[1][1], b[2][2]));
+    } else {
+        const double q = (b[0][0] + b[1][1] + b[2][2]) / 3.0;
+        const double p2 = (b[0][0] - q) * (b[0][0] - q) + (b[1][1] - q) * (b[1][1] - q) + (b[2][2] - q) * (b[2][2] - q) + 2.0 * p1;
+        const double p = std::sqrt(p2 / 6.0);
+        double c[3][3];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) c[i][j] = (b[i][j] - (i == j ? q : 0.0)) / p;
+        const double det = c[0][0] * (c[1][1] * c[2][2] - c[1][2] * c[2][1]) - c[0][1] * (c[1][0] * c[2][2] - c[1][2] * c[2][0]) +
+                           c[0][2] * (c[1][0] * c[2][1] - c[1][1] * c[2][0]);
+        const double r = std::min(1.0, std::max(-1.0, det / 2.0));
+        top = q + 2.0 * p * std::cos(std::acos(r) / 3.0);
+    }
+    return std::sqrt(std::max(top, 0.0));
+}
+
+// World-space bounding sphere of object i.  The object's transform is the inverse of the cached
+// inverse (affine: x -> A x + b), so an object-space point p lands at A^-1 (p - b).  The sphere
+// is centred on the image of (0, y_mid, 0); its radius is the largest singular value of A^-1
+// for a sphere and the farthest image of a corner of the enclosing box for a cube or a
+// cylinder (the farthest point of the image of a box is the image of a corner).  r = +inf when
+// the shape is unbounded or A is not invertible in double precision.
 void bounding_sphere(const rtx_scene_desc *d, uint32_t i, double c[3], double *r)
 {
     const double inf = std::numeric_limits<double>::infinity();
     c[0] = c[1] = c[2] = 0.0;
     *r = inf;
-    double ymid = 0.0, r_obj;
+    double ymid = 0.0, half_y = 1.0;
     const double lo = d->ymin[i], hi = d->ymax[i];
     switch (d->shape_type[i]) {
-    case RTX_SPHERE: r_obj = 1.0; break;
-    case RTX_CUBE: r_obj = std::sqrt(3.0); break;
+    case RTX_SPHERE:
+    case RTX_CUBE: break;
     case RTX_CYLINDER:
-        if (!std::isfinite(lo) || !std::isfinite(hi)) return;
+        // the reference's default limits are f64::MIN and f64::MAX (src/shapes/cylinders.rs:8)
+        if (!(std::fabs(lo) < 1e100) || !(std::fabs(hi) < 1e100)) return;
         ymid = 0.5 * (lo + hi);
-        r_obj = std::sqrt(1.0 + 0.25 * (hi - lo) * (hi - lo));
+        half_y = 0.5 * std::fabs(hi - lo);
         break;
     // A cone is never bounded: when the ray is parallel to one of its halves the reference
     // keeps the single root -c/(2b) without clipping it to [min, max] (src/shapes/cones.rs:44-52),
@@ -199,17 +288,33 @@ void bounding_sphere(const rtx_scene_desc *d, uint32_t i, double c[3], double *r
                             (a12 * a20 - a10 * a22) / det, (a00 * a22 - a02 * a20) / det, (a02 * a10 - a00 * a12) / det,
                             (a10 * a21 - a11 * a20) / det, (a01 * a20 - a00 * a21) / det, (a00 * a11 - a01 * a10) / det };
     const double v[3] = { 0.0 - m[3], ymid - m[7], 0.0 - m[11] };
-    double frob = 0.0;
-    for (int k = 0; k < 9; ++k) frob += inv[k] * inv[k];
-    frob = std::sqrt(frob);
-    for (int r3 = 0; r3 < 3; ++r3) c[r3] = inv[r3 * 3] * v[0] + inv[r3 * 3 + 1] * v[1] + inv[r3 * 3 + 2] * v[2];
-    const double rad = r_obj * frob;
-    if (!std::isfinite(rad) || !std::isfinite(c[0]) || !std::isfinite(c[1]) || !std::isfinite(c[2])) return;
+    for (int k = 0; k < 3; ++k) c[k] = inv[k * 3] * v[0] + inv[k * 3 + 1] * v[1] + inv[k * 3 + 2] * v[2];
+    double rad = 0.0;
+    if (d->shape_type[i] == RTX_SPHERE) {
+        rad = largest_singular_value(inv);
+    } else {
+        for (int corner = 0; corner < 8; ++corner) {
+            const double p[3] = { (corner & 1) ? 1.0 : -1.0, (corner & 2) ? half_y : -half_y, (corner & 4) ? 1.0 : -1.0 };
+            double q2 = 0.0;
+            for (int k = 0; k < 3; ++k) {
+                const double q = inv[k * 3] * p[0] + inv[k * 3 + 1] * p[1] + inv[k * 3 + 2] * p[2];
+                q2 += q * q;
+            }
+            if (!(q2 == q2)) return;
+            rad = std::max(rad, std::sqrt(q2));
+        }
+    }
+    rad *= 1.0 + 1e-9;
+    if (!std::isfinite(rad) || !std::isfinite(c[0]) || !std::isfinite(c[1]) || !std::isfinite(c[2])) {
+        c[0] = c[1] = c[2] = 0.0;
+        return;
+    }
     *r = rad;
 }
 
 template <typename R>
-void fill_tables(const rtx_scene_desc *d, const std::vector<uint8_t> &container, Tables<R> &t)
+void fill_tables(const rtx_scene_desc *d, const std::vector<uint8_t> &container, const std::vector<Bound> &bounds, bool cull,
+                 Tables<R> &t)
 {
     const uint32_t n = d->n_objects;
     t.cold.resize(n);
@@ -242,26 +347,41 @@ void fill_tables(const rtx_scene_desc *d, const std::vector<uint8_t> &container,
                   (container[i] ? OF_CONTAINER : 0u);
         c.pattern_type = d->pattern_type[i];
     }
-    // intersection tables: one per shape, World order kept inside each
-    for (uint32_t shape = RTX_SPHERE; shape <= RTX_CONE; ++shape)
-        for (uint32_t i = 0; i < n; ++i) {
-            if (d->shape_type[i] != shape) continue;
+    // intersection tables: one per shape
+    // inflation of a sphere stored as R: a relative part for the rounding of the test, an
+    // absolute part for the rounding of the centre
+    const double rel = sizeof(R) == 8 ? 1e-6 : 1e-3, ulp = sizeof(R) == 8 ? 1e-14 : 1e-6;
+    auto store = [&](const double c[3], double r) {
+        BoundRec<R> b;
+        const double cmax = std::max(std::fabs(c[0]), std::max(std::fabs(c[1]), std::fabs(c[2])));
+        for (int k = 0; k < 3; ++k) b.c[k] = (R)c[k];
+        b.r = std::isfinite(r) ? (R)(r * (1.0 + rel) + cmax * ulp) : (R)std::numeric_limits<double>::infinity();
+        return b;
+    };
+    for (uint32_t shape = RTX_SPHERE; shape <= RTX_CONE; ++shape) {
+        const std::vector<uint32_t> order = table_order(d, bounds, shape, cull);
+        t.cl_off[shape] = (uint32_t)t.cl.size();
+        for (size_t k0 = 0; cull && k0 < order.size(); k0 += kCluster) {
+            // cluster sphere: about the mean of the members' centres, reaching every member's sphere
+            const size_t k1 = std::min(order.size(), k0 + kCluster);
+            double c[3] = { 0, 0, 0 }, r = 0.0;
+            bool finite = true;
+            for (size_t k = k0; k < k1; ++k) {
+                finite = finite && std::isfinite(bounds[order[k]].r);
+                for (int a = 0; a < 3; ++a) c[a] += bounds[order[k]].c[a] / (double)(k1 - k0);
+            }
+            for (size_t k = k0; finite && k < k1; ++k) {
+                const Bound &m = bounds[order[k]];
+                const double dx = m.c[0] - c[0], dy = m.c[1] - c[1], dz = m.c[2] - c[2];
+                r = std::max(r, std::sqrt(dx * dx + dy * dy + dz * dz) * (1.0 + 1e-12) + m.r);
+            }
+            if (!finite) c[0] = c[1] = c[2] = 0.0;
+            t.cl.push_back(store(c, finite ? r : std::numeric_limits<double>::infinity()));
+        }
+        for (uint32_t i : order) {
             const double *inv = d->inverse + (size_t)i * 16;
             t.slot_obj.push_back(i);
-            {
-                double c[3], r;
-                bounding_sphere(d, i, c, &r);
-                BoundRec<R> b;
-                // inflation: covers the rounding of the test itself and of the centre
-                // inflation: a relative part for the rounding of the test, an absolute part for the
-                // rounding of the centre to R
-                const double rel = sizeof(R) == 8 ? 1e-6 : 1e-3, ulp = sizeof(R) == 8 ? 1e-14 : 1e-6;
-                const double cmax = std::max(std::fabs(c[0]), std::max(std::fabs(c[1]), std::fabs(c[2])));
-                for (int k = 0; k < 3; ++k) b.c[k] = (R)c[k];
-                b.r = std::isfinite(r) ? (R)(r * (1.0 + rel) + cmax * ulp) : (R)r;
-                if (std::isfinite((double)b.r)) t.n_bounded++;
-                t.bnd.push_back(b);
-            }
+            t.bnd.push_back(store(bounds[i].c, bounds[i].r));
             if (shape == RTX_SPHERE || shape == RTX_CUBE) {
                 XformRec<R> r;
                 for (int k = 0; k < 12; ++k) r.m[k] = (R)inv[k];
@@ -280,6 +400,7 @@ void fill_tables(const rtx_scene_desc *d, const std::vector<uint8_t> &container,
                 (shape == RTX_CYLINDER ? t.cyl : t.con).push_back(r);
             }
         }
+    }
 }
 
 // One device allocation per scene and precision holding all tables back to back.
@@ -290,8 +411,9 @@ int upload_tables(const Tables<R> &t, uint32_t sf, const rtx_scene_desc *d, void
     const size_t b_sph = pad(t.sph.size() * sizeof(XformRec<R>)), b_pln = pad(t.pln.size() * sizeof(PlaneRec<R>)),
                  b_cub = pad(t.cub.size() * sizeof(XformRec<R>)), b_cyl = pad(t.cyl.size() * sizeof(CappedRec<R>)),
                  b_con = pad(t.con.size() * sizeof(CappedRec<R>)), b_slot = pad(t.slot_obj.size() * sizeof(uint32_t)),
-                 b_cold = pad(t.cold.size() * sizeof(ColdRec<R>)), b_bnd = pad(t.bnd.size() * sizeof(BoundRec<R>));
-    const size_t total = b_sph + b_pln + b_cub + b_cyl + b_con + b_slot + b_cold + b_bnd + 256;
+                 b_cold = pad(t.cold.size() * sizeof(ColdRec<R>)), b_bnd = pad(t.bnd.size() * sizeof(BoundRec<R>)),
+                 b_cl = pad(t.cl.size() * sizeof(BoundRec<R>));
+    const size_t total = b_sph + b_pln + b_cub + b_cyl + b_con + b_slot + b_cold + b_bnd + b_cl + 256;
     std::vector<char> host(total, 0);
     size_t off = 0;
     auto put = [&](const void *src, size_t bytes, size_t padded) {
@@ -308,6 +430,7 @@ int upload_tables(const Tables<R> &t, uint32_t sf, const rtx_scene_desc *d, void
     const size_t o_slot = put(t.slot_obj.data(), t.slot_obj.size() * sizeof(uint32_t), b_slot);
     const size_t o_cold = put(t.cold.data(), t.cold.size() * sizeof(ColdRec<R>), b_cold);
     const size_t o_bnd = put(t.bnd.data(), t.bnd.size() * sizeof(BoundRec<R>), b_bnd);
+    const size_t o_cl = put(t.cl.data(), t.cl.size() * sizeof(BoundRec<R>), b_cl);
     HIP_TRY(hipMalloc(blob, total));
     HIP_TRY(hipMemcpy(*blob, host.data(), total, hipMemcpyHostToDevice));
     char *base = (char *)*blob;
@@ -320,7 +443,8 @@ int upload_tables(const Tables<R> &t, uint32_t sf, const rtx_scene_desc *d, void
     dev->slot_obj = (const uint32_t *)(base + o_slot);
     dev->cold = (const ColdRec<R> *)(base + o_cold);
     dev->bnd = (const BoundRec<R> *)(base + o_bnd);
-    dev->n_bounded = t.n_bounded;
+    dev->cl = (const BoundRec<R> *)(base + o_cl);
+    for (int k = 0; k < 5; ++k) dev->cl_off[k] = t.cl_off[k];
     dev->n_sph = (uint32_t)t.sph.size();
     dev->n_pln = (uint32_t)t.pln.size();
     dev->n_cub = (uint32_t)t.cub.size();
@@ -807,14 +931,16 @@ int rtx_scene_upload(rtx_context *ctx, const rtx_scene_desc *d, rtx_scene **out)
     std::unique_ptr<rtx_scene> s(new rtx_scene);
     s->ctx = ctx;
     s->n = n;
-    Tables<double> t64;
-    Tables<float> t32;
-    fill_tables<double>(d, container, t64);
-    fill_tables<float>(d, container, t32);
     // Bounding-sphere tests cost about 20 instructions per object and ray: they pay once most
     // rays miss most objects, which a handful of large objects in view does not give.
-    if (t64.n_bounded >= ctx->cull_min_objects) sf |= SF_CULL;
+    uint32_t n_bounded = 0;
+    const std::vector<Bound> bounds = scene_bounds(d, &n_bounded);
+    if (n_bounded >= ctx->cull_min_objects) sf |= SF_CULL;
     s->sf = sf;
+    Tables<double> t64;
+    Tables<float> t32;
+    fill_tables<double>(d, container, bounds, (sf & SF_CULL) != 0, t64);
+    fill_tables<float>(d, container, bounds, (sf & SF_CULL) != 0, t32);
     int rc = upload_tables<double>(t64, sf, d, &s->blob64, &s->dev64);
     if (!rc) rc = upload_tables<float>(t32, sf, d, &s->blob32, &s->dev32);
     if (rc) {

@@ -227,6 +227,7 @@ def frame_pair(orc, rta, scene_fn, depth=5, **kw):
     ("glass", dict(hsize=192, vsize=108)),
     ("glass", dict(hsize=96, vsize=54, n_lights=4)),
     ("random", dict(n_objects=300, hsize=160, vsize=90)),
+    ("random", dict(n_objects=3000, hsize=64, vsize=36)),  # ~100 clusters of bounding spheres
 ])
 def test_frame_matches_oracle(orc, rta, name, kw):
     from ray_tracer_amd import scenes
