@@ -337,21 +337,29 @@ template <typename Rec> RT_DEV Rec load_uniform(const Rec *p)
     return rec;
 }
 // keep.object(slot) says whether this lane's ray can hit the object at all; the record is fetched
-// only when some lane's can.  With Keep::clustered the slots are visited cluster by cluster and
-// keep.cluster(c) is asked first.
+// only when some lane's can.  With Keep::clustered the slots are visited group by group and
+// cluster by cluster, and keep.group(g) / keep.cluster(c) are asked first.
 template <typename Rec, typename Keep, typename Body>
-RT_DEV void walk_table(const Rec *recs, uint32_t n, uint32_t slot0, uint32_t cluster0, const Keep &keep, Body &&body)
+RT_DEV void walk_table(const Rec *recs, uint32_t n, uint32_t slot0, uint32_t cluster0, uint32_t group0, const Keep &keep,
+                       Body &&body)
 {
     if constexpr (Keep::clustered) {
-        for (uint32_t c = cluster0, i0 = 0; i0 < n; ++c, i0 += kCluster) {
-            const bool kc = keep.cluster(c);
-            if (__ballot(kc) == 0ull) continue;
-            const uint32_t i1 = (i0 + kCluster < n) ? i0 + kCluster : n;
-            for (uint32_t i = i0; i < i1; ++i) {
-                const bool k = kc && keep.object(slot0 + i);
-                if (__ballot(k) == 0ull) continue;
-                const Rec rec = load_uniform(recs + i);
-                if (k) body(rec, slot0 + i);
+        const uint32_t n_cl = (n + kCluster - 1) / kCluster;
+        for (uint32_t g = group0, c0 = 0; c0 < n_cl; ++g, c0 += kCluster) {
+            const bool kg = keep.group(g);
+            if (__ballot(kg) == 0ull) continue;
+            const uint32_t c1 = (c0 + kCluster < n_cl) ? c0 + kCluster : n_cl;
+            for (uint32_t c = c0; c < c1; ++c) {
+                const bool kc = kg && keep.cluster(cluster0 + c);
+                if (__ballot(kc) == 0ull) continue;
+                const uint32_t i0 = c * kCluster;
+                const uint32_t i1 = (i0 + kCluster < n) ? i0 + kCluster : n;
+                for (uint32_t i = i0; i < i1; ++i) {
+                    const bool k = kc && keep.object(slot0 + i);
+                    if (__ballot(k) == 0ull) continue;
+                    const Rec rec = load_uniform(recs + i);
+                    if (k) body(rec, slot0 + i);
+                }
             }
         }
     } else {
@@ -370,7 +378,7 @@ struct KeepAll {
 template <typename R, bool LINE>
 struct SphereCull {
     static constexpr bool clustered = true;
-    const BoundRec<R> *bnd, *cl;
+    const BoundRec<R> *bnd, *cl, *grp;
     CullRay<R> cr;
     const R *best;
     R limit;
@@ -378,6 +386,7 @@ struct SphereCull {
     RT_DEV R t_max() const { return best ? Num<R>::min_(*best, limit) : limit; }
     RT_DEV bool object(uint32_t slot) const { return !(stop && *stop) && may_hit<R, LINE>(load_uniform(bnd + slot), cr, t_max()); }
     RT_DEV bool cluster(uint32_t c) const { return !(stop && *stop) && may_hit<R, LINE>(load_uniform(cl + c), cr, t_max()); }
+    RT_DEV bool group(uint32_t g) const { return !(stop && *stop) && may_hit<R, LINE>(load_uniform(grp + g), cr, t_max()); }
 };
 
 // Object::intersect for every object of the world (src/shapes/objects.rs:185-198 with
@@ -388,20 +397,20 @@ template <typename R, typename Keep, typename Per>
 RT_DEV void walk_scene(const SceneDev<R> &S, V3<R> ro, V3<R> rd, const Keep &keep, Per &&per)
 {
     uint32_t slot0 = 0;
-    walk_table(S.sph, S.n_sph, slot0, S.cl_off[SH_SPHERE], keep, [&](const XformRec<R> &rec, uint32_t slot) {
+    walk_table(S.sph, S.n_sph, slot0, S.cl_off[SH_SPHERE], S.grp_off[SH_SPHERE], keep, [&](const XformRec<R> &rec, uint32_t slot) {
         const V3<R> o = xform_point(rec.m, ro);
         const V3<R> d = xform_vector(rec.m, rd);
         per(slot, [&](auto &&emit) { isect_sphere(o, d, sphere_c(o), emit); });
     });
     slot0 += S.n_sph;
-    walk_table(S.pln, S.n_pln, slot0, 0u, KeepAll(), [&](const PlaneRec<R> &rec, uint32_t slot) {
+    walk_table(S.pln, S.n_pln, slot0, 0u, 0u, KeepAll(), [&](const PlaneRec<R> &rec, uint32_t slot) {
         // only the y row of the object-space ray is read by planes.rs:11-17
         const R oy = ((rec.m[0] * ro.x + rec.m[1] * ro.y) + rec.m[2] * ro.z) + rec.m[3];
         const R dy = (rec.m[0] * rd.x + rec.m[1] * rd.y) + rec.m[2] * rd.z;
         per(slot, [&](auto &&emit) { isect_plane(-oy, dy, emit); });
     });
     slot0 += S.n_pln;
-    walk_table(S.cub, S.n_cub, slot0, S.cl_off[SH_CUBE], keep, [&](const XformRec<R> &rec, uint32_t slot) {
+    walk_table(S.cub, S.n_cub, slot0, S.cl_off[SH_CUBE], S.grp_off[SH_CUBE], keep, [&](const XformRec<R> &rec, uint32_t slot) {
         const V3<R> o = xform_point(rec.m, ro);
         const V3<R> d = xform_vector(rec.m, rd);
         const V3<R> lo = { R(-1) - o.x, R(-1) - o.y, R(-1) - o.z };
@@ -409,13 +418,13 @@ RT_DEV void walk_scene(const SceneDev<R> &S, V3<R> ro, V3<R> rd, const Keep &kee
         per(slot, [&](auto &&emit) { isect_cube(lo, hi, d, emit); });
     });
     slot0 += S.n_cub;
-    walk_table(S.cyl, S.n_cyl, slot0, S.cl_off[SH_CYLINDER], keep, [&](const CappedRec<R> &rec, uint32_t slot) {
+    walk_table(S.cyl, S.n_cyl, slot0, S.cl_off[SH_CYLINDER], S.grp_off[SH_CYLINDER], keep, [&](const CappedRec<R> &rec, uint32_t slot) {
         const V3<R> o = xform_point(rec.m, ro);
         const V3<R> d = xform_vector(rec.m, rd);
         per(slot, [&](auto &&emit) { isect_cylinder(o, twice(o), cylinder_c(o), d, rec.ymin, rec.ymax, rec.closed != 0, emit); });
     });
     slot0 += S.n_cyl;
-    walk_table(S.con, S.n_con, slot0, 0u, KeepAll(), [&](const CappedRec<R> &rec, uint32_t slot) {
+    walk_table(S.con, S.n_con, slot0, 0u, 0u, KeepAll(), [&](const CappedRec<R> &rec, uint32_t slot) {
         const V3<R> o = xform_point(rec.m, ro);
         const V3<R> d = xform_vector(rec.m, rd);
         per(slot, [&](auto &&emit) { isect_cone(o, twice(o), cone_c(o), d, rec.ymin, rec.ymax, rec.closed != 0, emit); });
@@ -435,32 +444,32 @@ template <typename R, typename Keep, typename Per>
 RT_DEV void walk_scene_primary(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> rd, const Keep &keep, Per &&per)
 {
     uint32_t slot0 = 0;
-    walk_table(P.sph, P.n_sph, slot0, S.cl_off[SH_SPHERE], keep, [&](const PrimSphereRec<R> &rec, uint32_t slot) {
+    walk_table(P.sph, P.n_sph, slot0, S.cl_off[SH_SPHERE], S.grp_off[SH_SPHERE], keep, [&](const PrimSphereRec<R> &rec, uint32_t slot) {
         const V3<R> o = { rec.o[0], rec.o[1], rec.o[2] };
         const V3<R> d = xform_vector9(rec.m, rd);
         per(slot, [&](auto &&emit) { isect_sphere(o, d, rec.c, emit); });
     });
     slot0 += P.n_sph;
-    walk_table(P.pln, P.n_pln, slot0, 0u, KeepAll(), [&](const PrimPlaneRec<R> &rec, uint32_t slot) {
+    walk_table(P.pln, P.n_pln, slot0, 0u, 0u, KeepAll(), [&](const PrimPlaneRec<R> &rec, uint32_t slot) {
         const R dy = (rec.m[0] * rd.x + rec.m[1] * rd.y) + rec.m[2] * rd.z;
         per(slot, [&](auto &&emit) { isect_plane(rec.neg_oy, dy, emit); });
     });
     slot0 += P.n_pln;
-    walk_table(P.cub, P.n_cub, slot0, S.cl_off[SH_CUBE], keep, [&](const PrimCubeRec<R> &rec, uint32_t slot) {
+    walk_table(P.cub, P.n_cub, slot0, S.cl_off[SH_CUBE], S.grp_off[SH_CUBE], keep, [&](const PrimCubeRec<R> &rec, uint32_t slot) {
         const V3<R> d = xform_vector9(rec.m, rd);
         const V3<R> lo = { rec.lo[0], rec.lo[1], rec.lo[2] };
         const V3<R> hi = { rec.hi[0], rec.hi[1], rec.hi[2] };
         per(slot, [&](auto &&emit) { isect_cube(lo, hi, d, emit); });
     });
     slot0 += P.n_cub;
-    walk_table(P.cyl, P.n_cyl, slot0, S.cl_off[SH_CYLINDER], keep, [&](const PrimCappedRec<R> &rec, uint32_t slot) {
+    walk_table(P.cyl, P.n_cyl, slot0, S.cl_off[SH_CYLINDER], S.grp_off[SH_CYLINDER], keep, [&](const PrimCappedRec<R> &rec, uint32_t slot) {
         const V3<R> o = { rec.o[0], rec.o[1], rec.o[2] };
         const V3<R> o2 = { rec.o2[0], rec.o2[1], rec.o2[2] };
         const V3<R> d = xform_vector9(rec.m, rd);
         per(slot, [&](auto &&emit) { isect_cylinder(o, o2, rec.c, d, rec.ymin, rec.ymax, rec.closed != 0, emit); });
     });
     slot0 += P.n_cyl;
-    walk_table(P.con, P.n_con, slot0, 0u, KeepAll(), [&](const PrimCappedRec<R> &rec, uint32_t slot) {
+    walk_table(P.con, P.n_con, slot0, 0u, 0u, KeepAll(), [&](const PrimCappedRec<R> &rec, uint32_t slot) {
         const V3<R> o = { rec.o[0], rec.o[1], rec.o[2] };
         const V3<R> o2 = { rec.o2[0], rec.o2[1], rec.o2[2] };
         const V3<R> d = xform_vector9(rec.m, rd);
@@ -605,7 +614,7 @@ RT_DEV Hit<R> closest_hit(const SceneDev<R> &S, V3<R> ro, V3<R> rd, R t_limit)
 {
     if constexpr (CULL) {
         return closest_hit_with<R, TRACK>(S, [&](const R *best, auto &&per) {
-            const SphereCull<R, TRACK> keep = { S.bnd, S.cl, cull_ray(ro, rd), best, t_limit, nullptr };
+            const SphereCull<R, TRACK> keep = { S.bnd, S.cl, S.grp, cull_ray(ro, rd), best, t_limit, nullptr };
             walk_scene(S, ro, rd, keep, per);
         });
     } else {
@@ -617,7 +626,7 @@ RT_DEV Hit<R> closest_hit_primary(const SceneDev<R> &S, const PrimScene<R> &P, V
 {
     if constexpr (CULL) {
         return closest_hit_with<R, TRACK>(S, [&](const R *best, auto &&per) {
-            const SphereCull<R, TRACK> keep = { S.bnd, S.cl, cull_ray(ro, rd), best, Num<R>::inf, nullptr };
+            const SphereCull<R, TRACK> keep = { S.bnd, S.cl, S.grp, cull_ray(ro, rd), best, Num<R>::inf, nullptr };
             walk_scene_primary(S, P, rd, keep, per);
         });
     } else {
@@ -640,7 +649,7 @@ RT_DEV bool is_shadowed(const SceneDev<R> &S, V3<R> p, V3<R> dir, R distance)
             });
         };
         if constexpr (CULL) {
-            const SphereCull<R, false> keep = { S.bnd, S.cl, cull_ray(p, dir), nullptr, distance, &shadowed };
+            const SphereCull<R, false> keep = { S.bnd, S.cl, S.grp, cull_ray(p, dir), nullptr, distance, &shadowed };
             walk_scene(S, p, dir, keep, per);
         } else {
             walk_scene(S, p, dir, KeepAll(), per);

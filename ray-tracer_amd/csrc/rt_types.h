@@ -54,10 +54,16 @@ struct alignas(sizeof(R) * 4) BoundRec {
     R c[3];
     R r;
 };
-// When the bounding-sphere tests are on, the slots of a shape table are ordered along a
-// space-filling curve and every kCluster consecutive slots share one more bounding sphere, so
-// a ray tests n / kCluster cluster spheres and then only the members of the clusters it meets.
-constexpr uint32_t kCluster = 32;
+// When the bounding-sphere tests are on, the slots of a shape table are ordered by a k-d
+// partition of the objects' centres whose cuts fall on multiples of kCluster (and of kCluster^2
+// higher up): every kCluster consecutive slots are neighbours in space and share one more
+// bounding sphere (a cluster), every kCluster consecutive clusters share a third (a group).
+// A ray tests n / kCluster^2 group spheres, then the clusters of the groups it meets, then the
+// members of the clusters it meets.
+#ifndef RTX_CLUSTER
+#define RTX_CLUSTER 16
+#endif
+constexpr uint32_t kCluster = RTX_CLUSTER;
 
 // ---- primary-ray tables -----------------------------------------------------------------
 // Every primary ray starts at the camera, so each object's object-space ray origin and the
@@ -129,8 +135,9 @@ struct SceneDev {
     const CappedRec<R> *con;
     const BoundRec<R> *bnd;    // by slot
     const BoundRec<R> *cl;     // cluster spheres; those of shape s start at cl_off[s]
+    const BoundRec<R> *grp;    // group spheres; those of shape s start at grp_off[s]
     uint32_t cl_off[5];
-    uint32_t pad;
+    uint32_t grp_off[5];
     const uint32_t *slot_obj;  // slot -> index in World.objects (the tie-break order among equal t)
     const ColdRec<R> *cold;    // by index in World.objects
     uint32_t n_sph, n_pln, n_cub, n_cyl, n_con;

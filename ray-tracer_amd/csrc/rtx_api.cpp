@@ -160,8 +160,8 @@ struct Tables {
     std::vector<XformRec<R>> sph, cub;
     std::vector<PlaneRec<R>> pln;
     std::vector<CappedRec<R>> cyl, con;
-    std::vector<BoundRec<R>> bnd, cl;
-    uint32_t cl_off[5] = { 0, 0, 0, 0, 0 };
+    std::vector<BoundRec<R>> bnd, cl, grp;
+    uint32_t cl_off[5] = { 0, 0, 0, 0, 0 }, grp_off[5] = { 0, 0, 0, 0, 0 };
     std::vector<uint32_t> slot_obj;
     std::vector<ColdRec<R>> cold;
 };
@@ -184,47 +184,59 @@ std::vector<Bound> scene_bounds(const rtx_scene_desc *d, uint32_t *n_bounded)
 }
 
 // Order of the objects of one shape inside its table.  Without the bounding-sphere tests it is
-// the World's order.  With them, bounded objects come first, sorted along a Morton curve through
-// their centres so that consecutive slots are neighbours in space; unbounded ones follow.  The
-// order inside a table is free: ties between equal t are settled by World index, not by slot.
+// the World's order.  With them, bounded objects come first in the order of the leaves of a k-d
+// partition of their centres (longest axis of the box, cut near the median at a multiple of
+// kCluster, or of kCluster^2 while more than that many remain), so that every aligned run of
+// kCluster slots, and of kCluster^2 slots, is compact in space; unbounded ones follow.  The order
+// inside a table is free: ties between equal t are settled by World index, not by slot.
+void kd_order(std::vector<uint32_t> &idx, size_t lo, size_t hi, const std::vector<Bound> &bounds)
+{
+    const size_t n = hi - lo;
+    if (n <= kCluster) return;
+    const size_t unit = n > (size_t)kCluster * kCluster ? (size_t)kCluster * kCluster : kCluster;
+    const size_t half = ((n / 2 + unit - 1) / unit) * unit;  // 0 < half < n
+    double bl[3] = { 1e300, 1e300, 1e300 }, bh[3] = { -1e300, -1e300, -1e300 };
+    for (size_t k = lo; k < hi; ++k)
+        for (int a = 0; a < 3; ++a) {
+            bl[a] = std::min(bl[a], bounds[idx[k]].c[a]);
+            bh[a] = std::max(bh[a], bounds[idx[k]].c[a]);
+        }
+    int axis = 0;
+    for (int a = 1; a < 3; ++a)
+        if (bh[a] - bl[a] > bh[axis] - bl[axis]) axis = a;
+    std::nth_element(idx.begin() + lo, idx.begin() + lo + half, idx.begin() + hi, [&](uint32_t x, uint32_t y) {
+        return bounds[x].c[axis] < bounds[y].c[axis] || (bounds[x].c[axis] == bounds[y].c[axis] && x < y);
+    });
+    kd_order(idx, lo, lo + half, bounds);
+    kd_order(idx, lo + half, hi, bounds);
+}
+
 std::vector<uint32_t> table_order(const rtx_scene_desc *d, const std::vector<Bound> &bounds, uint32_t shape, bool cull)
 {
-    std::vector<uint32_t> idx;
+    std::vector<uint32_t> idx, unbounded;
     for (uint32_t i = 0; i < d->n_objects; ++i)
-        if (d->shape_type[i] == shape) idx.push_back(i);
-    if (!cull || idx.empty()) return idx;
-    double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
-    for (uint32_t i : idx)
-        if (std::isfinite(bounds[i].r))
-            for (int k = 0; k < 3; ++k) {
-                lo[k] = std::min(lo[k], bounds[i].c[k]);
-                hi[k] = std::max(hi[k], bounds[i].c[k]);
-            }
-    auto spread = [](uint64_t v) {  // 21 bits -> every third bit
-        v &= 0x1fffffull;
-        v = (v | v << 32) & 0x1f00000000ffffull;
-        v = (v | v << 16) & 0x1f0000ff0000ffull;
-        v = (v | v << 8) & 0x100f00f00f00f00full;
-        v = (v | v << 4) & 0x10c30c30c30c30c3ull;
-        v = (v | v << 2) & 0x1249249249249249ull;
-        return v;
-    };
-    std::vector<std::pair<uint64_t, uint32_t>> keyed;
-    for (uint32_t i : idx) {
-        uint64_t key = ~0ull;  // unbounded objects last
-        if (std::isfinite(bounds[i].r)) {
-            key = 0;
-            for (int k = 0; k < 3; ++k) {
-                const double span = hi[k] - lo[k];
-                const double u = span > 0.0 ? (bounds[i].c[k] - lo[k]) / span : 0.0;
-                key |= spread((uint64_t)(std::min(std::max(u, 0.0), 1.0) * 2097151.0)) << k;
-            }
-        }
-        keyed.emplace_back(key, i);
-    }
-    std::stable_sort(keyed.begin(), keyed.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
-    for (size_t k = 0; k < keyed.size(); ++k) idx[k] = keyed[k].second;
+        if (d->shape_type[i] == shape) (!cull || std::isfinite(bounds[i].r) ? idx : unbounded).push_back(i);
+    if (!cull) return idx;
+    kd_order(idx, 0, idx.size(), bounds);
+    idx.insert(idx.end(), unbounded.begin(), unbounded.end());
     return idx;
+}
+
+// Sphere about the mean of the members' centres that reaches every member's sphere.
+Bound enclosing_sphere(const Bound *members, size_t n)
+{
+    Bound out = { { 0, 0, 0 }, std::numeric_limits<double>::infinity() };
+    for (size_t k = 0; k < n; ++k)
+        if (!std::isfinite(members[k].r)) return out;
+    for (size_t k = 0; k < n; ++k)
+        for (int a = 0; a < 3; ++a) out.c[a] += members[k].c[a] / (double)n;
+    double r = 0.0;
+    for (size_t k = 0; k < n; ++k) {
+        const double dx = members[k].c[0] - out.c[0], dy = members[k].c[1] - out.c[1], dz = members[k].c[2] - out.c[2];
+        r = std::max(r, std::sqrt(dx * dx + dy * dy + dz * dz) * (1.0 + 1e-12) + members[k].r);
+    }
+    out.r = r;
+    return out;
 }
 
 // Largest singular value of a 3x3 matrix (row-major): square root of the largest eigenvalue of
@@ -361,22 +373,17 @@ void fill_tables(const rtx_scene_desc *d, const std::vector<uint8_t> &container,
     for (uint32_t shape = RTX_SPHERE; shape <= RTX_CONE; ++shape) {
         const std::vector<uint32_t> order = table_order(d, bounds, shape, cull);
         t.cl_off[shape] = (uint32_t)t.cl.size();
-        for (size_t k0 = 0; cull && k0 < order.size(); k0 += kCluster) {
-            // cluster sphere: about the mean of the members' centres, reaching every member's sphere
-            const size_t k1 = std::min(order.size(), k0 + kCluster);
-            double c[3] = { 0, 0, 0 }, r = 0.0;
-            bool finite = true;
-            for (size_t k = k0; k < k1; ++k) {
-                finite = finite && std::isfinite(bounds[order[k]].r);
-                for (int a = 0; a < 3; ++a) c[a] += bounds[order[k]].c[a] / (double)(k1 - k0);
+        t.grp_off[shape] = (uint32_t)t.grp.size();
+        if (cull) {
+            std::vector<Bound> members, clusters;
+            for (uint32_t i : order) members.push_back(bounds[i]);
+            for (size_t k0 = 0; k0 < members.size(); k0 += kCluster)
+                clusters.push_back(enclosing_sphere(members.data() + k0, std::min<size_t>(kCluster, members.size() - k0)));
+            for (const Bound &c : clusters) t.cl.push_back(store(c.c, c.r));
+            for (size_t k0 = 0; k0 < clusters.size(); k0 += kCluster) {
+                const Bound g = enclosing_sphere(clusters.data() + k0, std::min<size_t>(kCluster, clusters.size() - k0));
+                t.grp.push_back(store(g.c, g.r));
             }
-            for (size_t k = k0; finite && k < k1; ++k) {
-                const Bound &m = bounds[order[k]];
-                const double dx = m.c[0] - c[0], dy = m.c[1] - c[1], dz = m.c[2] - c[2];
-                r = std::max(r, std::sqrt(dx * dx + dy * dy + dz * dz) * (1.0 + 1e-12) + m.r);
-            }
-            if (!finite) c[0] = c[1] = c[2] = 0.0;
-            t.cl.push_back(store(c, finite ? r : std::numeric_limits<double>::infinity()));
         }
         for (uint32_t i : order) {
             const double *inv = d->inverse + (size_t)i * 16;
@@ -412,8 +419,8 @@ int upload_tables(const Tables<R> &t, uint32_t sf, const rtx_scene_desc *d, void
                  b_cub = pad(t.cub.size() * sizeof(XformRec<R>)), b_cyl = pad(t.cyl.size() * sizeof(CappedRec<R>)),
                  b_con = pad(t.con.size() * sizeof(CappedRec<R>)), b_slot = pad(t.slot_obj.size() * sizeof(uint32_t)),
                  b_cold = pad(t.cold.size() * sizeof(ColdRec<R>)), b_bnd = pad(t.bnd.size() * sizeof(BoundRec<R>)),
-                 b_cl = pad(t.cl.size() * sizeof(BoundRec<R>));
-    const size_t total = b_sph + b_pln + b_cub + b_cyl + b_con + b_slot + b_cold + b_bnd + b_cl + 256;
+                 b_cl = pad(t.cl.size() * sizeof(BoundRec<R>)), b_grp = pad(t.grp.size() * sizeof(BoundRec<R>));
+    const size_t total = b_sph + b_pln + b_cub + b_cyl + b_con + b_slot + b_cold + b_bnd + b_cl + b_grp + 256;
     std::vector<char> host(total, 0);
     size_t off = 0;
     auto put = [&](const void *src, size_t bytes, size_t padded) {
@@ -431,6 +438,7 @@ int upload_tables(const Tables<R> &t, uint32_t sf, const rtx_scene_desc *d, void
     const size_t o_cold = put(t.cold.data(), t.cold.size() * sizeof(ColdRec<R>), b_cold);
     const size_t o_bnd = put(t.bnd.data(), t.bnd.size() * sizeof(BoundRec<R>), b_bnd);
     const size_t o_cl = put(t.cl.data(), t.cl.size() * sizeof(BoundRec<R>), b_cl);
+    const size_t o_grp = put(t.grp.data(), t.grp.size() * sizeof(BoundRec<R>), b_grp);
     HIP_TRY(hipMalloc(blob, total));
     HIP_TRY(hipMemcpy(*blob, host.data(), total, hipMemcpyHostToDevice));
     char *base = (char *)*blob;
@@ -444,7 +452,11 @@ int upload_tables(const Tables<R> &t, uint32_t sf, const rtx_scene_desc *d, void
     dev->cold = (const ColdRec<R> *)(base + o_cold);
     dev->bnd = (const BoundRec<R> *)(base + o_bnd);
     dev->cl = (const BoundRec<R> *)(base + o_cl);
-    for (int k = 0; k < 5; ++k) dev->cl_off[k] = t.cl_off[k];
+    dev->grp = (const BoundRec<R> *)(base + o_grp);
+    for (int k = 0; k < 5; ++k) {
+        dev->cl_off[k] = t.cl_off[k];
+        dev->grp_off[k] = t.grp_off[k];
+    }
     dev->n_sph = (uint32_t)t.sph.size();
     dev->n_pln = (uint32_t)t.pln.size();
     dev->n_cub = (uint32_t)t.cub.size();
