@@ -124,6 +124,10 @@ int rtx_context_set_cull_threshold(rtx_context *ctx, uint32_t min_bounded_object
  * there are objects but no light. */
 int rtx_scene_upload(rtx_context *ctx, const rtx_scene_desc *desc, rtx_scene **out);
 void rtx_scene_destroy(rtx_scene *scene);
+/* Which kernel specialisation the scene selected: bit 0 some object reflects, bit 1 some object is
+ * transparent, bit 2 every object casts a shadow, bit 3 some object has a pattern, bit 4 the
+ * bounding-sphere tests are on.  For reports; no counterpart in the reference. */
+int rtx_scene_features(const rtx_scene *scene, uint32_t *bits);
 
 /*
  * Replaces the body of Camera::parallel_render (src/scenes/camera.rs:172-201, max_depth 5),

@@ -90,6 +90,7 @@ rtx_context_set_workspace_limit = _bind("rtx_context_set_workspace_limit", C.c_i
 rtx_context_set_cull_threshold = _bind("rtx_context_set_cull_threshold", C.c_int, [_vp, C.c_uint32])
 rtx_scene_upload = _bind("rtx_scene_upload", C.c_int, [_vp, C.POINTER(SceneDesc), C.POINTER(_vp)])
 rtx_scene_destroy = _bind("rtx_scene_destroy", None, [_vp])
+rtx_scene_features = _bind("rtx_scene_features", C.c_int, [_vp, C.POINTER(C.c_uint32)])
 rtx_render = _bind("rtx_render", C.c_int, [_vp, _vp, C.POINTER(CameraDesc), C.c_uint32, C.c_int, C.c_uint32, C.c_uint32,
                                            _vp, C.c_size_t, _vp, _vp, C.POINTER(Stats)])
 rtx_render_device = _bind("rtx_render_device", C.c_int, [_vp, _vp, C.POINTER(CameraDesc), C.c_uint32, C.c_int, C.c_uint32,
@@ -103,7 +104,7 @@ rtx_device_info = _bind("rtx_device_info", C.c_int, [_vp, C.c_char_p, C.c_size_t
 # every symbol include/rtx.h declares
 RTX_SYMBOLS = ["rtx_last_error", "rtx_context_create", "rtx_context_destroy", "rtx_context_set_workspace_limit",
                "rtx_context_set_cull_threshold",
-               "rtx_scene_upload", "rtx_scene_destroy", "rtx_render", "rtx_render_device", "rtx_trace_rays",
+               "rtx_scene_upload", "rtx_scene_destroy", "rtx_scene_features", "rtx_render", "rtx_render_device", "rtx_trace_rays",
                "rtx_probe_rays", "rtx_generate_rays", "rtx_quantize_u8_device", "rtx_device_info"]
 
 
@@ -287,6 +288,14 @@ class Scene:
         h = _vp()
         _check(rtx_scene_upload(ctx.h, C.byref(d), C.byref(h)))
         self.h = h
+
+    def features(self):
+        """Feature bits of the kernel specialisation this scene selected (rtx_scene_features)."""
+        bits = C.c_uint32()
+        _check(rtx_scene_features(self.h, C.byref(bits)))
+        v = bits.value
+        return dict(reflective=bool(v & 1), transparent=bool(v & 2), all_cast_shadows=bool(v & 4), patterns=bool(v & 8),
+                    bounding_sphere_tests=bool(v & 16))
 
     def close(self):
         if self.h:

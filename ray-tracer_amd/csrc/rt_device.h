@@ -47,7 +47,7 @@ template <> struct Num<double> {
 // reciprocal, square root, exp2 and log2, and formulations that stay accurate in 24 bits.
 template <> struct Num<float> {
     static constexpr bool exact = false;
-    static constexpr float cull_slack = 4e-6f;
+    static constexpr float cull_slack = 1e-6f;  // md and tc * tc each carry about 3 roundings of 6e-8
     static constexpr float eps = 0.00001f;
     static constexpr float big = 3.402823466e38f;
     static constexpr float inf = __builtin_huge_valf();
@@ -291,6 +291,7 @@ struct CullRay {
     V3<R> o, d;
     R d2;    // d . d
     R dlen;  // |d|
+    bool dead;  // the ray holds a NaN: it cannot hit anything
 };
 template <typename R> RT_DEV CullRay<R> cull_ray(V3<R> o, V3<R> d)
 {
@@ -299,6 +300,11 @@ template <typename R> RT_DEV CullRay<R> cull_ray(V3<R> o, V3<R> d)
     c.d = d;
     c.d2 = dot3(d, d);
     c.dlen = Num<R>::sqrt_(c.d2);
+    // A NaN anywhere in the ray reaches every object-space coordinate (0 * NaN is NaN), so every
+    // t of every shape is NaN and nothing is hit; without this the sphere tests, whose
+    // comparisons are all false on NaN, would let such a ray through to all objects.
+    const R oo = dot3(o, o);
+    c.dead = !(c.d2 == c.d2) || !(oo == oo);
     return c;
 }
 // LINE: intersections anywhere on the line count (the container bookkeeping of refraction reads
@@ -306,6 +312,7 @@ template <typename R> RT_DEV CullRay<R> cull_ray(V3<R> o, V3<R> d)
 template <typename R, bool LINE>
 RT_DEV bool may_hit(const BoundRec<R> &b, const CullRay<R> &cr, R t_max)
 {
+    if (cr.dead) return false;
     const V3<R> m = { b.c[0] - cr.o.x, b.c[1] - cr.o.y, b.c[2] - cr.o.z };
     const R tc = dot3(m, cr.d);
     const R m2 = dot3(m, m);

@@ -963,6 +963,13 @@ int rtx_scene_upload(rtx_context *ctx, const rtx_scene_desc *d, rtx_scene **out)
     return RTX_OK;
 }
 
+int rtx_scene_features(const rtx_scene *scene, uint32_t *bits)
+{
+    if (!scene || !bits) return fail(RTX_ERR_INVALID, "scene or bits is NULL");
+    *bits = scene->sf;
+    return RTX_OK;
+}
+
 void rtx_scene_destroy(rtx_scene *s)
 {
     if (!s) return;
