@@ -222,20 +222,33 @@ std::vector<uint32_t> table_order(const rtx_scene_desc *d, const std::vector<Bou
     return idx;
 }
 
-// Sphere about the mean of the members' centres that reaches every member's sphere.
+// Sphere that reaches every member's sphere: centred on the mean of the members' centres or on
+// the centre of the box around the members' spheres, whichever needs the smaller radius.
 Bound enclosing_sphere(const Bound *members, size_t n)
 {
     Bound out = { { 0, 0, 0 }, std::numeric_limits<double>::infinity() };
     for (size_t k = 0; k < n; ++k)
         if (!std::isfinite(members[k].r)) return out;
+    double mean[3] = { 0, 0, 0 }, lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
     for (size_t k = 0; k < n; ++k)
-        for (int a = 0; a < 3; ++a) out.c[a] += members[k].c[a] / (double)n;
-    double r = 0.0;
-    for (size_t k = 0; k < n; ++k) {
-        const double dx = members[k].c[0] - out.c[0], dy = members[k].c[1] - out.c[1], dz = members[k].c[2] - out.c[2];
-        r = std::max(r, std::sqrt(dx * dx + dy * dy + dz * dz) * (1.0 + 1e-12) + members[k].r);
+        for (int a = 0; a < 3; ++a) {
+            mean[a] += members[k].c[a] / (double)n;
+            lo[a] = std::min(lo[a], members[k].c[a] - members[k].r);
+            hi[a] = std::max(hi[a], members[k].c[a] + members[k].r);
+        }
+    const double mid[3] = { 0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2]) };
+    const double *centres[2] = { mean, mid };
+    for (const double *c : centres) {
+        double r = 0.0;
+        for (size_t k = 0; k < n; ++k) {
+            const double dx = members[k].c[0] - c[0], dy = members[k].c[1] - c[1], dz = members[k].c[2] - c[2];
+            r = std::max(r, std::sqrt(dx * dx + dy * dy + dz * dz) * (1.0 + 1e-12) + members[k].r);
+        }
+        if (r < out.r) {
+            out.r = r;
+            for (int a = 0; a < 3; ++a) out.c[a] = c[a];
+        }
     }
-    out.r = r;
     return out;
 }
 
