@@ -216,6 +216,10 @@ def main():
     t_h = time.perf_counter()
     rta._check(rta.rtx_render(ctx.h, scene.h, cd, args.depth, prec, r0, r1, host.ctypes.data, host.nbytes, None, None, None))
     host_ms = (time.perf_counter() - t_h) * 1e3
+    rgba = np.empty((r1 - r0, args.width, 4), dtype=np.uint8)
+    t_h = time.perf_counter()
+    rta._check(rta.rtx_render_8bit(ctx.h, scene.h, cd, args.depth, prec, r0, r1, 4, rgba.ctypes.data, rgba.nbytes, None, None, None))
+    host_rgba8_ms = (time.perf_counter() - t_h) * 1e3
 
     vals = torch.tensor([wall, float(st["color_rays"]), float(st["shadow_rays"])], dtype=torch.float64, device="cuda")
     if world_size > 1:
@@ -277,6 +281,7 @@ def main():
                 "device_ms_per_frame": dev_ms,
                 "color_only_Mrays_per_s": color_rays / (ms_per_step * 1e-3) / 1e6,
                 "host_copy_inclusive_ms": host_ms,
+                "host_rgba8_inclusive_ms": host_rgba8_ms,
                 "launches_per_frame": st["n_launches"],
             },
         }

@@ -143,6 +143,17 @@ int rtx_render(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_desc *
                rtx_progress_fn progress, void *user, rtx_stats *stats);
 
 /*
+ * rtx_render followed by the reference's 8-bit conversion, done on the device so that only
+ * bytes cross PCIe: channels = 3 gives Canvas::canvas_to_png's RGB (src/scenes/canvas.rs:80-92),
+ * channels = 4 gives Canvas::canvas_to_buffer's RGBA with alpha 255 (canvas.rs:94-104, what the
+ * GUI displays); every channel is `(c * 255.999) as u8` (saturating, NaN -> 0).  out holds
+ * (row_end-row_begin)*hsize*channels bytes, row-major.
+ */
+int rtx_render_8bit(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_desc *camera, uint32_t max_depth,
+                    int precision, uint32_t row_begin, uint32_t row_end, uint32_t channels, uint8_t *out, size_t out_bytes,
+                    rtx_progress_fn progress, void *user, rtx_stats *stats);
+
+/*
  * Same as rtx_render with the output left in device memory (d_out_rgb is a device pointer
  * with room for the same number of values).  `stream` is a hipStream_t (NULL = the context's
  * own stream); the call returns once the kernels are enqueued unless stats is non-NULL, in

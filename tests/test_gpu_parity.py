@@ -312,6 +312,41 @@ def test_bounding_sphere_tests_change_nothing(orc, rta):
         assert np.allclose(a[3], b[3], rtol=0.0, atol=1e-12, equal_nan=True), "case %d" % i
 
 
+def test_8bit_output_matches_the_reference_conversion(orc, rta):
+    """rtx_render_8bit = render + `(c * 255.999) as u8` on the device (src/scenes/canvas.rs:80-104):
+    identical to converting the f64 frame on the host; RGBA carries alpha 255; partial row ranges
+    and the f32 path work too."""
+    from ray_tracer_amd import scenes
+    ctx = rta.Context()
+    for fn, kw in [(scenes.default_scene, dict(hsize=131, vsize=77)), (scenes.spheres_on_plane, dict(hsize=96, vsize=54)),
+                   (shapes_scene, dict(kind=0))]:
+        w, cam = fn(rta.api, **kw)
+        scene = rta.Scene(ctx, rta.flatten(w))
+        cd = rta.camera_desc(cam)
+        H, W = cd.vsize, cd.hsize
+        full = np.empty((H, W, 3))
+        rta._check(rta.rtx_render(ctx.h, scene.h, cd, 5, rta.F64, 0, H, full.ctypes.data, full.nbytes, None, None, None))
+        want = orc.quantize_u8(full)
+        for channels in (3, 4):
+            got = np.zeros((H, W, channels), dtype=np.uint8)
+            rta._check(rta.rtx_render_8bit(ctx.h, scene.h, cd, 5, rta.F64, 0, H, channels, got.ctypes.data, got.nbytes, None, None, None))
+            assert np.array_equal(got[:, :, :3], want)
+            if channels == 4:
+                assert (got[:, :, 3] == 255).all()
+        part = np.zeros((H - 13, W, 3), dtype=np.uint8)
+        rta._check(rta.rtx_render_8bit(ctx.h, scene.h, cd, 5, rta.F64, 10, H - 3, 3, part.ctypes.data, part.nbytes, None, None, None))
+        assert np.array_equal(part, want[10:H - 3])
+        f32 = np.zeros((H, W, 4), dtype=np.uint8)
+        rta._check(rta.rtx_render_8bit(ctx.h, scene.h, cd, 5, rta.F32, 0, H, 4, f32.ctypes.data, f32.nbytes, None, None, None))
+        assert (np.abs(f32[:, :, :3].astype(int) - want.astype(int)).max(axis=2) <= 1).mean() >= 0.999
+        with pytest.raises(rta.RtxError):
+            rta._check(rta.rtx_render_8bit(ctx.h, scene.h, cd, 5, rta.F64, 0, H, 2, got.ctypes.data, got.nbytes, None, None, None))
+        with pytest.raises(rta.RtxError):
+            rta._check(rta.rtx_render_8bit(ctx.h, scene.h, cd, 5, rta.F64, 0, H, 4, got.ctypes.data, 16, None, None, None))
+        scene.close()
+    ctx.close()
+
+
 def test_f32_fast_path(orc, rta):
     """f32 colours within 1/255 after 8-bit quantisation (src/scenes/canvas.rs:84-86) on at
     least 99.9 % of the pixels, against the f64 oracle."""
