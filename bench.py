@@ -212,14 +212,17 @@ def main():
         k_primary.append(s2["primary_kernel_ms"])
         k_all.append(s2["kernel_ms"])
     # host-visible frame: render + copy to a host buffer (PCIe included), for the record
-    host = np.empty((r1 - r0, args.width, 3), dtype=np.float64 if prec == rta.F64 else np.float32)
-    t_h = time.perf_counter()
-    rta._check(rta.rtx_render(ctx.h, scene.h, cd, args.depth, prec, r0, r1, host.ctypes.data, host.nbytes, None, None, None))
-    host_ms = (time.perf_counter() - t_h) * 1e3
-    rgba = np.empty((r1 - r0, args.width, 4), dtype=np.uint8)
-    t_h = time.perf_counter()
-    rta._check(rta.rtx_render_8bit(ctx.h, scene.h, cd, args.depth, prec, r0, r1, 4, rgba.ctypes.data, rgba.nbytes, None, None, None))
-    host_rgba8_ms = (time.perf_counter() - t_h) * 1e3
+    # (buffers zero-filled first, as Canvas::new does: the copy is not charged their page faults)
+    host = np.zeros((r1 - r0, args.width, 3), dtype=np.float64 if prec == rta.F64 else np.float32)
+    rgba = np.zeros((r1 - r0, args.width, 4), dtype=np.uint8)
+    host_ms = host_rgba8_ms = float("inf")
+    for _ in range(3):
+        t_h = time.perf_counter()
+        rta._check(rta.rtx_render(ctx.h, scene.h, cd, args.depth, prec, r0, r1, host.ctypes.data, host.nbytes, None, None, None))
+        host_ms = min(host_ms, (time.perf_counter() - t_h) * 1e3)
+        t_h = time.perf_counter()
+        rta._check(rta.rtx_render_8bit(ctx.h, scene.h, cd, args.depth, prec, r0, r1, 4, rgba.ctypes.data, rgba.nbytes, None, None, None))
+        host_rgba8_ms = min(host_rgba8_ms, (time.perf_counter() - t_h) * 1e3)
 
     vals = torch.tensor([wall, float(st["color_rays"]), float(st["shadow_rays"])], dtype=torch.float64, device="cuda")
     if world_size > 1:

@@ -18,7 +18,7 @@ if [[ "$what" == "lib" || "$what" == "all" ]]; then
   g++ $COMMON -ffp-contract=off -fno-fast-math -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -c "$PKG/host/rt.cpp" -o "$PKG/build/rt.o" &
   g++ $COMMON -ffp-contract=off -fno-fast-math -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -c "$PKG/host/rt_capi.cpp" -o "$PKG/build/rt_capi.o" &
   for job in $(jobs -p); do wait "$job" || { echo "error: a compile step failed"; exit 1; }; done
-  "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/$LIBNAME" "$PKG/build/render_f64.o" "$PKG/build/render_f32.o" \
+  "$HIPCC" --offload-arch=gfx950 -shared -fPIC -pthread -o "$OUT/$LIBNAME" "$PKG/build/render_f64.o" "$PKG/build/render_f32.o" \
       "$PKG/build/rtx_api.o" "$PKG/build/rt.o" "$PKG/build/rt_capi.o"
   echo "built $OUT/$LIBNAME"
 fi

@@ -17,6 +17,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rtx.h"
@@ -68,6 +69,8 @@ struct Slot {
     hipEvent_t done = nullptr;  // recorded when a call returns with work still in flight
     bool pending = false;
     bool busy = false;
+    char *pin[2] = { nullptr, nullptr };  // pinned staging buffers for large copies to pageable memory
+    hipEvent_t pin_ev[2] = { nullptr, nullptr };
 };
 
 }  // namespace
@@ -151,6 +154,49 @@ int grow(void **ptr, size_t *have, size_t need)
     *have = 0;
     HIP_TRY(hipMalloc(ptr, need));
     *have = need;
+    return RTX_OK;
+}
+
+// Device -> pageable host memory.  hipMemcpy stages such a copy through pinned memory with one
+// CPU thread (about 10-18 GB/s here); two pinned buffers, the DMA of one overlapping the memcpy
+// out of the other, and four threads on the memcpy reach about 50 GB/s.  Blocks until the data
+// is in dst.
+constexpr size_t kPinBytes = (size_t)16 << 20;
+constexpr int kCopyThreads = 4;
+int copy_to_host(Slot *slot, hipStream_t stream, void *dst, const void *src, size_t bytes)
+{
+    if (bytes < 2 * kPinBytes) {
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        return RTX_OK;
+    }
+    for (int k = 0; k < 2; ++k) {
+        if (!slot->pin[k]) HIP_TRY(hipHostMalloc((void **)&slot->pin[k], kPinBytes, hipHostMallocDefault));
+        if (!slot->pin_ev[k]) HIP_TRY(hipEventCreateWithFlags(&slot->pin_ev[k], hipEventDisableTiming));
+    }
+    const size_t n = (bytes + kPinBytes - 1) / kPinBytes;
+    auto issue = [&](size_t i) -> hipError_t {
+        const size_t len = std::min(kPinBytes, bytes - i * kPinBytes);
+        hipError_t e = hipMemcpyAsync(slot->pin[i & 1], (const char *)src + i * kPinBytes, len, hipMemcpyDeviceToHost, stream);
+        return e != hipSuccess ? e : hipEventRecord(slot->pin_ev[i & 1], stream);
+    };
+    HIP_TRY(issue(0));
+    for (size_t i = 0; i < n; ++i) {
+        HIP_TRY(hipEventSynchronize(slot->pin_ev[i & 1]));
+        if (i + 1 < n) HIP_TRY(issue(i + 1));  // lands in the other buffer while this one is copied out
+        const size_t len = std::min(kPinBytes, bytes - i * kPinBytes);
+        const size_t part = (len / kCopyThreads + 4095) & ~(size_t)4095;
+        char *out = (char *)dst + i * kPinBytes;
+        const char *in = slot->pin[i & 1];
+        std::thread helpers[kCopyThreads - 1];
+        for (int k = 1; k < kCopyThreads; ++k) {
+            const size_t a = (size_t)k * part;
+            if (a < len) helpers[k - 1] = std::thread([=] { std::memcpy(out + a, in + a, std::min(part, len - a)); });
+        }
+        std::memcpy(out, in, std::min(part, len));
+        for (auto &h : helpers)
+            if (h.joinable()) h.join();
+    }
     return RTX_OK;
 }
 
@@ -773,9 +819,11 @@ int render_impl(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_desc 
         rc = grow(&slot->aux, &slot->aux_bytes, (size_t)(n_pix * channels8));
         if (rc) return rc;
         HIP_TRY(Launch<R>::pack8(stream, d_fb, (uint32_t)n_pix, channels8, (uint8_t *)slot->aux));
-        HIP_TRY(hipMemcpyAsync(host_out, slot->aux, (size_t)(n_pix * channels8), hipMemcpyDeviceToHost, stream));
+        rc = copy_to_host(slot, stream, host_out, slot->aux, (size_t)(n_pix * channels8));
+        if (rc) return rc;
     } else if (host_out) {
-        HIP_TRY(hipMemcpyAsync(host_out, d_fb, (size_t)(n_pix * 3 * sizeof(R)), hipMemcpyDeviceToHost, stream));
+        rc = copy_to_host(slot, stream, host_out, d_fb, (size_t)(n_pix * 3 * sizeof(R)));
+        if (rc) return rc;
     }
     HIP_TRY(hipStreamSynchronize(stream));
     rc = collect_stats(slot, n_chunks, n_pix, true, stats);
@@ -887,6 +935,10 @@ void rtx_context_destroy(rtx_context *ctx)
             if (s->counts) (void)hipFree(s->counts);
             if (s->shards) (void)hipFree(s->shards);
             if (s->done) (void)hipEventDestroy(s->done);
+            for (int k = 0; k < 2; ++k) {
+                if (s->pin[k]) (void)hipHostFree(s->pin[k]);
+                if (s->pin_ev[k]) (void)hipEventDestroy(s->pin_ev[k]);
+            }
             for (auto &e : s->ev)
                 if (e) (void)hipEventDestroy(e);
             if (s->stream) (void)hipStreamDestroy(s->stream);
