@@ -39,8 +39,10 @@ FP32_VECTOR_PEAK_TFLOPS = 157.3  # packed FP32 vector peak
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    # a frame of the headline scene takes ~70 us: 2000 of them amortise the ~2 ms the GPU needs to
+    # come out of idle after the fence that precedes the timed region
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--scene", default="default", choices=["default", "spheres_on_plane", "glass", "random"])
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
