@@ -27,6 +27,7 @@ enum {
 
 typedef struct rt_object rt_object;
 typedef struct rt_world rt_world;
+typedef struct rt_group rt_group;
 typedef struct rt_camera rt_camera;
 
 const char *rt_last_panic(void);
@@ -68,6 +69,22 @@ rt_world *rt_world_new(void);
 rt_world *rt_world_default(void);
 void rt_world_free(rt_world *w);
 int rt_world_add_object(rt_world *w, const rt_object *o);
+/* Group, src/shapes/groups.rs:5-55, 86-111; adding copies (Rust moves the value in) */
+rt_group *rt_group_new(void);                                                /* groups.rs:30-43 */
+void rt_group_free(rt_group *g);
+int rt_group_add_object(rt_group *g, const rt_object *o);                    /* groups.rs:49-51 */
+int rt_group_add_group(rt_group *g, const rt_group *child);                  /* groups.rs:53-55 */
+int rt_group_n_elements(const rt_group *g);
+int rt_group_set_transform(rt_group *g, const double *m16);                  /* groups.rs:88-92 */
+int rt_group_set_transformation_list(rt_group *g, int index, double x);      /* groups.rs:94-97 */
+int rt_group_transform_op(rt_group *g, int slot, double x);                  /* traits.rs:46-98 */
+void rt_group_get_matrices(const rt_group *g, double *transform, double *inverse, double *inverse_t);
+/* World::add_group, world.rs:82-84: appends the group's objects, depth first, as the copies with
+ * merged transformation lists that Group::local_intersect returns (groups.rs:73-84); returns the
+ * index of the first, -1 on panic */
+int rt_world_add_group(rt_world *w, const rt_group *g);
+/* number of groups around object `index` and their inverse transforms, outermost first */
+int rt_world_object_chain(const rt_world *w, int index, double *inverses16, int cap);
 void rt_world_add_light(rt_world *w, const double *pos3, const double *intensity3);
 void rt_world_clear_lights(rt_world *w);
 int rt_world_n_objects(const rt_world *w);
@@ -86,7 +103,9 @@ enum {
     RT_FLAT_YRANGE = 5,   /* ymin, ymax per object */
     RT_FLAT_TAGS = 6,     /* shape, closed, casts_shadow, pattern_type, eq_class per object */
     RT_FLAT_LIGHTS = 7,   /* position xyz, intensity rgb per light */
-    RT_FLAT_PATTERN_COLORS = 8 /* color1 rgb, color2 rgb per object */
+    RT_FLAT_PATTERN_COLORS = 8, /* color1 rgb, color2 rgb per object */
+    RT_FLAT_CHAIN = 9,         /* chain_depth, chain_first per object */
+    RT_FLAT_CHAIN_INVERSE = 10 /* the chain_inverse matrices, 16 values each */
 };
 int64_t rt_world_flat(const rt_world *w, int field, double *out, int64_t cap);
 

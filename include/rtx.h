@@ -76,6 +76,18 @@ typedef struct rtx_scene_desc {
     uint32_t n_lights;
     const double *light_position;       /* [n_lights][3] */
     const double *light_intensity;      /* [n_lights][3] */
+    /* Objects inside Groups (src/shapes/groups.rs:68-84, src/shapes/objectholders.rs:36-41), flattened
+     * depth first, which is the order the nested stable sorts leave equal t in.  For such an object
+     * the entries above (inverse, inverse_transposed, material, eq_class) describe the copy the
+     * reference returns in its Intersections -- the child with every enclosing group's
+     * transformation list merged in (combine_transforms, src/shapes/traits.rs:35-44, innermost group
+     * first) -- which is what normals, patterns and the container list use.  The ray itself reaches
+     * the child through chain_depth[i] + 1 matrices starting at chain_inverse[chain_first[i]]: the
+     * inverse_transform of each enclosing group, outermost first, then the inverse_transform of the
+     * child as it was added.  chain_depth == NULL: no groups.  At most 3 levels of nesting. */
+    const uint8_t *chain_depth;         /* [n] enclosing groups (0 = plain object), or NULL */
+    const uint32_t *chain_first;        /* [n] index of the object's first matrix in chain_inverse */
+    const double *chain_inverse;        /* [..][16] */
 } rtx_scene_desc;
 
 /* The Camera fields ray_for_pixel reads (src/scenes/camera.rs:5-15, 147-158). */

@@ -717,8 +717,22 @@ static color_t lighting(const material_t *material, const orc_object *object, li
 /* ------------------------------------------------------------------------------------
  * world (scenes/world.rs)
  * ---------------------------------------------------------------------------------- */
+/* An Object that sits inside Groups (groups.rs:68-84).  The ray reaches it through the inverse
+ * of every enclosing group, outermost first, one Ray::transform per level; the Object handed
+ * back in its Intersections is a copy whose transformation list was merged with each group's
+ * list (combine_transforms, traits.rs:35-44), innermost group first.  That copy does not depend
+ * on the ray, so it is made once when the group is added: it is what World.objects[i] holds for
+ * such a leaf, while `base` keeps the child as it was added, for the intersection itself. */
+#define ORC_MAX_GROUP_DEPTH 8
+typedef struct {
+    int depth; /* 0: a plain Object of the World */
+    mat4_t inverse[ORC_MAX_GROUP_DEPTH];
+    orc_object base;
+} chain_t;
+
 struct orc_world {
     orc_object *objects;
+    chain_t *chains; /* parallel to objects */
     int n_objects, cap_objects;
     light_t *lights;
     int n_lights, cap_lights;
@@ -783,7 +797,15 @@ static size_t intersect_world(const orc_world *w, ray_t ray, trace_ctx *ctx)
     size_t n = 0;
     for (int i = 0; i < w->n_objects; i++) {
         double ts[4];
-        int k = object_intersect(&w->objects[i], ray, ts);
+        int k;
+        const chain_t *ch = &w->chains[i];
+        if (ch->depth == 0) {
+            k = object_intersect(&w->objects[i], ray, ts);
+        } else { /* Group::intersect, groups.rs:68-71, level by level, then the child's own intersect */
+            ray_t local = ray;
+            for (int g = 0; g < ch->depth; g++) local = ray_transform(local, &ch->inverse[g]);
+            k = object_intersect(&ch->base, local, ts);
+        }
         ctx_reserve(ctx, n + 4);
         for (int j = 0; j < k; j++) {
             ctx->xs[n].t = ts[j];
@@ -1210,17 +1232,241 @@ void orc_world_free(orc_world *w)
 {
     if (!w) return;
     free(w->objects);
+    free(w->chains);
     free(w->lights);
     free(w);
 }
-int orc_world_add_object(orc_world *w, const orc_object *o)
+static int world_push(orc_world *w, const orc_object *o)
 {
     if (w->n_objects == w->cap_objects) {
         w->cap_objects = w->cap_objects ? 2 * w->cap_objects : 16;
         w->objects = (orc_object *)realloc(w->objects, (size_t)w->cap_objects * sizeof(orc_object));
+        w->chains = (chain_t *)realloc(w->chains, (size_t)w->cap_objects * sizeof(chain_t));
+        if (!w->objects || !w->chains) { fprintf(stderr, "rt_oracle: out of memory\n"); abort(); }
     }
     w->objects[w->n_objects] = *o;
+    w->chains[w->n_objects].depth = 0;
     return w->n_objects++;
+}
+int orc_world_add_object(orc_world *w, const orc_object *o) { return world_push(w, o); }
+
+/* ---- groups (groups.rs, objectholders.rs) ---- */
+typedef struct {
+    int is_group;
+    orc_object object;
+    orc_group *group;
+} holder_t;
+struct orc_group {
+    holder_t *items;
+    int n, cap;
+    mat4_t transform, inverse, inverse_t;
+    double tlist[15];
+};
+/* groups.rs:27-43 */
+orc_group *orc_group_new(void)
+{
+    orc_group *g = (orc_group *)calloc(1, sizeof(orc_group));
+    g->transform = m4_identity();
+    g->inverse = m4_identity();
+    g->inverse_t = m4_identity();
+    g->tlist[3] = g->tlist[4] = g->tlist[5] = 1.0;
+    return g;
+}
+void orc_group_free(orc_group *g)
+{
+    if (!g) return;
+    for (int i = 0; i < g->n; i++)
+        if (g->items[i].is_group) orc_group_free(g->items[i].group);
+    free(g->items);
+    free(g);
+}
+static orc_group *group_clone(const orc_group *g)
+{
+    orc_group *c = (orc_group *)malloc(sizeof(orc_group));
+    *c = *g;
+    c->items = (holder_t *)malloc((size_t)(g->cap ? g->cap : 1) * sizeof(holder_t));
+    for (int i = 0; i < g->n; i++) {
+        c->items[i] = g->items[i];
+        if (g->items[i].is_group) c->items[i].group = group_clone(g->items[i].group);
+    }
+    return c;
+}
+static holder_t *group_slot(orc_group *g)
+{
+    if (g->n == g->cap) {
+        g->cap = g->cap ? 2 * g->cap : 8;
+        g->items = (holder_t *)realloc(g->items, (size_t)g->cap * sizeof(holder_t));
+    }
+    return &g->items[g->n++];
+}
+/* groups.rs:49-55: values are moved in, i.e. the group owns copies */
+int orc_group_add_object(orc_group *g, const orc_object *o)
+{
+    holder_t *h = group_slot(g);
+    h->is_group = 0;
+    h->object = *o;
+    h->group = NULL;
+    return g->n - 1;
+}
+int orc_group_add_group(orc_group *g, const orc_group *child)
+{
+    holder_t *h = group_slot(g);
+    h->is_group = 1;
+    h->group = group_clone(child);
+    return g->n - 1;
+}
+int orc_group_n_elements(const orc_group *g) { return g->n; }
+size_t orc_object_sizeof(void) { return sizeof(orc_object); }
+/* groups.rs:88-92 */
+static void group_set_transform(orc_group *g, mat4_t t)
+{
+    g->transform = t;
+    g->inverse = m4_invert(t);
+    g->inverse_t = m4_transpose(g->inverse);
+}
+int orc_group_set_transform(orc_group *g, const double *m16)
+{
+    API_ENTER();
+    group_set_transform(g, m4_load(m16));
+    API_LEAVE();
+    return ORC_OK;
+}
+/* groups.rs:94-97 with traits.rs:8-33 */
+int orc_group_set_transformation_list(orc_group *g, int index, double x)
+{
+    API_ENTER();
+    if (index < 0 || index >= 15) panic("index out of bounds (transformations_list)");
+    g->tlist[index] = x;
+    const double *l = g->tlist;
+    mat4_t t = translation(l[0], l[1], l[2]);
+    mat4_t sc = scaling(l[3], l[4], l[5]);
+    mat4_t rx = rotation_x(l[6]), ry = rotation_y(l[7]), rz = rotation_z(l[8]);
+    mat4_t sh = shearing(l[9], l[10], l[11], l[12], l[13], l[14]);
+    group_set_transform(g, m4_mul(m4_mul(m4_mul(m4_mul(m4_mul(t, sc), rx), ry), rz), sh));
+    API_LEAVE();
+    return ORC_OK;
+}
+/* traits.rs:46-98: scale_x/y/z replace 0 by EPSILON */
+int orc_group_transform_op(orc_group *g, int slot, double x)
+{
+    if (slot >= 3 && slot <= 5 && !(x != 0.0)) x = EPSILON;
+    return orc_group_set_transformation_list(g, slot, x);
+}
+void orc_group_get_matrices(const orc_group *g, double *transform, double *inverse, double *inverse_t)
+{
+    if (transform) m4_store(g->transform, transform);
+    if (inverse) m4_store(g->inverse, inverse);
+    if (inverse_t) m4_store(g->inverse_t, inverse_t);
+}
+/* traits.rs:35-44 */
+static void object_combine_transforms(orc_object *o, const double *list)
+{
+    for (int i = 0; i < 15; i++) {
+        if (i <= 2 || i >= 6) o->tlist[i] += list[i];
+        else o->tlist[i] *= list[i];
+    }
+    object_update_transform(o);
+}
+/* Group::intersect + local_intersect, groups.rs:68-84, as written: recursive, every level sorts.
+ * Returns the number of intersections appended at out[n0..]; objs receives the merged copies. */
+typedef struct { double t; orc_object object; } gisect_t;
+static int group_intersect(const orc_group *g, ray_t ray, gisect_t **out, int *cap, int n0)
+{
+    ray_t local = ray_transform(ray, &g->inverse);
+    int n = n0;
+    for (int i = 0; i < g->n; i++) {
+        int first = n;
+        if (g->items[i].is_group) {
+            n = group_intersect(g->items[i].group, local, out, cap, n);
+        } else {
+            double ts[4];
+            int k = object_intersect(&g->items[i].object, local, ts);
+            if (n + k > *cap) {
+                *cap = 2 * (*cap) + 16;
+                *out = (gisect_t *)realloc(*out, (size_t)*cap * sizeof(gisect_t));
+            }
+            for (int j = 0; j < k; j++) {
+                (*out)[n].t = ts[j];
+                (*out)[n].object = g->items[i].object;
+                n++;
+            }
+        }
+        for (int j = first; j < n; j++) object_combine_transforms(&(*out)[j].object, g->tlist);
+    }
+    /* vec.sort_by(partial_cmp().unwrap()): stable, panics on NaN */
+    gisect_t *a = *out + n0;
+    int m = n - n0;
+    for (int i = 0; i < m; i++)
+        if (a[i].t != a[i].t) panic("called `Option::unwrap()` on a `None` value (NaN t in sort)");
+    for (int i = 1; i < m; i++) {
+        gisect_t key = a[i];
+        int j = i;
+        while (j > 0 && a[j - 1].t > key.t) { a[j] = a[j - 1]; j--; }
+        a[j] = key;
+    }
+    return n;
+}
+int orc_group_intersect(const orc_group *g, const double *ray6, double *out_t, orc_object *out_objects, int cap)
+{
+    gisect_t *xs = NULL;
+    int xcap = 0, n = -1;
+    jmp_buf jb;
+    jmp_buf *saved = tl_jmp;
+    if (setjmp(jb)) { tl_jmp = saved; free(xs); return -1; }
+    tl_jmp = &jb;
+    n = group_intersect(g, ray_load(ray6), &xs, &xcap, 0);
+    for (int i = 0; i < n && i < cap; i++) {
+        if (out_t) out_t[i] = xs[i].t;
+        if (out_objects) out_objects[i] = xs[i].object;
+    }
+    tl_jmp = saved;
+    free(xs);
+    return n;
+}
+/* World::add_group, world.rs:82-84.  The leaves are laid out depth first, which is the order
+ * the nested stable sorts leave equal t in. */
+static void world_add_leaves(orc_world *w, const orc_group *g, chain_t *chain, const double **lists)
+{
+    if (chain->depth >= ORC_MAX_GROUP_DEPTH) panic("groups nested deeper than this restatement supports");
+    chain->inverse[chain->depth] = g->inverse;
+    lists[chain->depth] = g->tlist;
+    chain->depth++;
+    for (int i = 0; i < g->n; i++) {
+        if (g->items[i].is_group) {
+            world_add_leaves(w, g->items[i].group, chain, lists);
+        } else {
+            orc_object merged = g->items[i].object;
+            for (int d = chain->depth - 1; d >= 0; d--) object_combine_transforms(&merged, lists[d]);
+            int idx = world_push(w, &merged);
+            w->chains[idx] = *chain;
+            w->chains[idx].base = g->items[i].object;
+        }
+    }
+    chain->depth--;
+}
+int orc_world_add_group(orc_world *w, const orc_group *g)
+{
+    API_ENTER();
+    chain_t chain;
+    const double *lists[ORC_MAX_GROUP_DEPTH];
+    memset(&chain, 0, sizeof chain);
+    int first = w->n_objects;
+    world_add_leaves(w, g, &chain, lists);
+    API_LEAVE();
+    return first;
+}
+/* depth of the group chain above World.objects[index] and the inverse of each group, outermost first */
+int orc_world_object_chain(const orc_world *w, int index, double *inverses16, int cap)
+{
+    if (index < 0 || index >= w->n_objects) return -1;
+    const chain_t *ch = &w->chains[index];
+    for (int d = 0; d < ch->depth && d < cap; d++) m4_store(ch->inverse[d], inverses16 + 16 * d);
+    return ch->depth;
+}
+const orc_object *orc_world_object_base(const orc_world *w, int index)
+{
+    if (index < 0 || index >= w->n_objects) return NULL;
+    return w->chains[index].depth ? &w->chains[index].base : &w->objects[index];
 }
 void orc_world_add_light(orc_world *w, const double *pos3, const double *in3)
 {

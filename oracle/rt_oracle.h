@@ -18,6 +18,7 @@
 #ifndef RT_ORACLE_H
 #define RT_ORACLE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -39,6 +40,7 @@ enum {
 
 typedef struct orc_object orc_object;
 typedef struct orc_world orc_world;
+typedef struct orc_group orc_group;
 typedef struct orc_camera orc_camera;
 
 const char *orc_last_panic(void);
@@ -96,6 +98,25 @@ orc_world *orc_world_new(void);
 orc_world *orc_world_default(void);
 void orc_world_free(orc_world *w);
 int orc_world_add_object(orc_world *w, const orc_object *o); /* copies; returns index */
+/* Group, src/shapes/groups.rs; ObjectHolder, src/shapes/objectholders.rs.  Adding copies. */
+orc_group *orc_group_new(void);
+void orc_group_free(orc_group *g);
+int orc_group_add_object(orc_group *g, const orc_object *o);
+int orc_group_add_group(orc_group *g, const orc_group *child);
+int orc_group_n_elements(const orc_group *g);
+size_t orc_object_sizeof(void); /* bytes of one orc_object, for callers that receive copies */
+int orc_group_set_transform(orc_group *g, const double *m16);
+int orc_group_set_transformation_list(orc_group *g, int index, double x);
+int orc_group_transform_op(orc_group *g, int slot, double x);
+void orc_group_get_matrices(const orc_group *g, double *transform, double *inverse, double *inverse_t);
+/* Group::intersect as written (recursive, every level sorts); out_objects receives the copies
+ * with merged transformation lists; returns the count, -1 on panic */
+int orc_group_intersect(const orc_group *g, const double *ray6, double *out_t, orc_object *out_objects, int cap);
+/* World::add_group (world.rs:82-84): returns the index of the group's first leaf in the
+ * flattened object list */
+int orc_world_add_group(orc_world *w, const orc_group *g);
+int orc_world_object_chain(const orc_world *w, int index, double *inverses16, int cap);
+const orc_object *orc_world_object_base(const orc_world *w, int index);
 void orc_world_add_light(orc_world *w, const double *pos3, const double *intensity3);
 void orc_world_clear_lights(orc_world *w);
 int orc_world_n_objects(const orc_world *w);

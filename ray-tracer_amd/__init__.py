@@ -63,7 +63,8 @@ class SceneDesc(C.Structure):
                 ("specular", _dp), ("shininess", _dp), ("reflective", _dp), ("transparency", _dp),
                 ("refractive_index", _dp), ("casts_shadow", _u8p), ("pattern_type", _u8p), ("pattern_inverse", _dp),
                 ("pattern_color1", _dp), ("pattern_color2", _dp), ("eq_class", _u32p), ("n_lights", C.c_uint32),
-                ("light_position", _dp), ("light_intensity", _dp)]
+                ("light_position", _dp), ("light_intensity", _dp), ("chain_depth", _u8p), ("chain_first", _u32p),
+                ("chain_inverse", _dp)]
 
 
 class CameraDesc(C.Structure):
@@ -133,7 +134,7 @@ _rt_camera_parallel_render = _bind("rt_camera_parallel_render", C.c_int, [_vp, _
                                                                           C.POINTER(Stats)])
 
 FLAT_INVERSE, FLAT_INVERSE_T, FLAT_PATTERN_INVERSE, FLAT_COLOR, FLAT_MATERIAL, FLAT_YRANGE, FLAT_TAGS, FLAT_LIGHTS, \
-    FLAT_PATTERN_COLORS = range(9)
+    FLAT_PATTERN_COLORS, FLAT_CHAIN, FLAT_CHAIN_INVERSE = range(11)
 
 
 def _rays(rays):
@@ -257,6 +258,10 @@ def flatten(world):
         light_position=np.ascontiguousarray(lights[:, :3]).reshape(-1),
         light_intensity=np.ascontiguousarray(lights[:, 3:]).reshape(-1),
     )
+    chain = flat(world, FLAT_CHAIN).reshape(n, 2)
+    if chain[:, 0].any():
+        d.update(chain_depth=chain[:, 0].astype(np.uint8), chain_first=chain[:, 1].astype(np.uint32),
+                 chain_inverse=flat(world, FLAT_CHAIN_INVERSE))
     return d
 
 

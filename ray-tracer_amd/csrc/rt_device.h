@@ -400,7 +400,39 @@ struct SphereCull {
 // src/rays.rs:30-34): the ray goes into object space (direction not renormalised), then the
 // per-shape routine runs.  For each object `per(slot, run)` is called once; `run(emit)`
 // performs the intersection and calls emit(t) per intersection.
-template <typename R, typename Keep, typename Per>
+// Objects inside groups: the ray goes through the chain level by level (Group::intersect,
+// src/shapes/groups.rs:68-71, then Object::intersect, objects.rs:185-188).
+template <typename R, typename Per>
+RT_DEV void walk_chained(const SceneDev<R> &S, V3<R> ro, V3<R> rd, Per &&per)
+{
+    const uint32_t slot0 = S.n - S.n_chn;
+    for (uint32_t i = 0; i < S.n_chn; ++i) {
+        const ChainRec<R> rec = load_uniform(S.chn + i);
+        V3<R> o = ro, d = rd;
+        for (uint32_t k = 0; k <= rec.depth && k <= kMaxChain; ++k) {
+            const V3<R> o2 = xform_point(rec.m[k], o);
+            d = xform_vector(rec.m[k], d);
+            o = o2;
+        }
+        per(slot0 + i, [&](auto &&emit) {
+            if (rec.type == SH_SPHERE) {
+                isect_sphere(o, d, sphere_c(o), emit);
+            } else if (rec.type == SH_PLANE) {
+                isect_plane(-o.y, d.y, emit);
+            } else if (rec.type == SH_CUBE) {
+                const V3<R> lo = { R(-1) - o.x, R(-1) - o.y, R(-1) - o.z };
+                const V3<R> hi = { R(1) - o.x, R(1) - o.y, R(1) - o.z };
+                isect_cube(lo, hi, d, emit);
+            } else if (rec.type == SH_CYLINDER) {
+                isect_cylinder(o, twice(o), cylinder_c(o), d, rec.ymin, rec.ymax, rec.closed != 0, emit);
+            } else {
+                isect_cone(o, twice(o), cone_c(o), d, rec.ymin, rec.ymax, rec.closed != 0, emit);
+            }
+        });
+    }
+}
+
+template <typename R, bool CHAIN, typename Keep, typename Per>
 RT_DEV void walk_scene(const SceneDev<R> &S, V3<R> ro, V3<R> rd, const Keep &keep, Per &&per)
 {
     uint32_t slot0 = 0;
@@ -436,6 +468,7 @@ RT_DEV void walk_scene(const SceneDev<R> &S, V3<R> ro, V3<R> rd, const Keep &kee
         const V3<R> d = xform_vector(rec.m, rd);
         per(slot, [&](auto &&emit) { isect_cone(o, twice(o), cone_c(o), d, rec.ymin, rec.ymax, rec.closed != 0, emit); });
     });
+    if constexpr (CHAIN) walk_chained(S, ro, rd, per);
 }
 
 // The same walk for primary rays: they all start at the camera, so the object-space origin
@@ -447,8 +480,8 @@ template <typename R> RT_DEV V3<R> xform_vector9(const R *m, V3<R> v)
              (m[3] * v.x + m[4] * v.y) + m[5] * v.z,
              (m[6] * v.x + m[7] * v.y) + m[8] * v.z };
 }
-template <typename R, typename Keep, typename Per>
-RT_DEV void walk_scene_primary(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> rd, const Keep &keep, Per &&per)
+template <typename R, bool CHAIN, typename Keep, typename Per>
+RT_DEV void walk_scene_primary(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> ro, V3<R> rd, const Keep &keep, Per &&per)
 {
     uint32_t slot0 = 0;
     walk_table(P.sph, P.n_sph, slot0, S.cl_off[SH_SPHERE], S.grp_off[SH_SPHERE], keep, [&](const PrimSphereRec<R> &rec, uint32_t slot) {
@@ -482,6 +515,7 @@ RT_DEV void walk_scene_primary(const SceneDev<R> &S, const PrimScene<R> &P, V3<R
         const V3<R> d = xform_vector9(rec.m, rd);
         per(slot, [&](auto &&emit) { isect_cone(o, o2, rec.c, d, rec.ymin, rec.ymax, rec.closed != 0, emit); });
     });
+    if constexpr (CHAIN) walk_chained(S, ro, rd, per);
 }
 
 // Fill the primary-ray table entry of one slot from the scene tables and the camera origin.
@@ -616,28 +650,28 @@ RT_DEV Hit<R> closest_hit_with(const SceneDev<R> &S, Walk &&walk)
 }
 // The closest-hit walks.  t_limit: hits beyond it need not be found (inf for color_at; the
 // distance to the light for a shadow ray, which only asks whether the closest hit lies before it).
-template <typename R, bool TRACK, bool CULL>
+template <typename R, bool TRACK, bool CULL, bool CHAIN>
 RT_DEV Hit<R> closest_hit(const SceneDev<R> &S, V3<R> ro, V3<R> rd, R t_limit)
 {
     if constexpr (CULL) {
         return closest_hit_with<R, TRACK>(S, [&](const R *best, auto &&per) {
             const SphereCull<R, TRACK> keep = { S.bnd, S.cl, S.grp, cull_ray(ro, rd), best, t_limit, nullptr };
-            walk_scene(S, ro, rd, keep, per);
+            walk_scene<R, CHAIN>(S, ro, rd, keep, per);
         });
     } else {
-        return closest_hit_with<R, TRACK>(S, [&](const R *, auto &&per) { walk_scene(S, ro, rd, KeepAll(), per); });
+        return closest_hit_with<R, TRACK>(S, [&](const R *, auto &&per) { walk_scene<R, CHAIN>(S, ro, rd, KeepAll(), per); });
     }
 }
-template <typename R, bool TRACK, bool CULL>
+template <typename R, bool TRACK, bool CULL, bool CHAIN>
 RT_DEV Hit<R> closest_hit_primary(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> ro, V3<R> rd)
 {
     if constexpr (CULL) {
         return closest_hit_with<R, TRACK>(S, [&](const R *best, auto &&per) {
             const SphereCull<R, TRACK> keep = { S.bnd, S.cl, S.grp, cull_ray(ro, rd), best, Num<R>::inf, nullptr };
-            walk_scene_primary(S, P, rd, keep, per);
+            walk_scene_primary<R, CHAIN>(S, P, ro, rd, keep, per);
         });
     } else {
-        return closest_hit_with<R, TRACK>(S, [&](const R *, auto &&per) { walk_scene_primary(S, P, rd, KeepAll(), per); });
+        return closest_hit_with<R, TRACK>(S, [&](const R *, auto &&per) { walk_scene_primary<R, CHAIN>(S, P, ro, rd, KeepAll(), per); });
     }
 }
 
@@ -648,6 +682,7 @@ template <typename R, uint32_t SF>
 RT_DEV bool is_shadowed(const SceneDev<R> &S, V3<R> p, V3<R> dir, R distance)
 {
     constexpr bool CULL = (SF & SF_CULL) != 0;
+    constexpr bool CHAIN = (SF & SF_CHAIN) != 0;
     if constexpr ((SF & SF_ALL_CAST) != 0) {
         bool shadowed = false;
         auto per = [&](uint32_t, auto &&run) {
@@ -657,13 +692,13 @@ RT_DEV bool is_shadowed(const SceneDev<R> &S, V3<R> p, V3<R> dir, R distance)
         };
         if constexpr (CULL) {
             const SphereCull<R, false> keep = { S.bnd, S.cl, S.grp, cull_ray(p, dir), nullptr, distance, &shadowed };
-            walk_scene(S, p, dir, keep, per);
+            walk_scene<R, CHAIN>(S, p, dir, keep, per);
         } else {
-            walk_scene(S, p, dir, KeepAll(), per);
+            walk_scene<R, CHAIN>(S, p, dir, KeepAll(), per);
         }
         return shadowed;
     } else {
-        Hit<R> h = closest_hit<R, false, CULL>(S, p, dir, distance);
+        Hit<R> h = closest_hit<R, false, CULL, CHAIN>(S, p, dir, distance);
         if (h.slot == kNone) return false;
         return h.t < distance && (S.cold[h.obj].flags & OF_CASTS_SHADOW) != 0;
     }
@@ -754,8 +789,9 @@ RT_DEV Node<R> trace_node(const SceneDev<R> &S, const PrimScene<R> *P, V3<R> ro,
     nd.lighting = { R(0), R(0), R(0) };
     Hit<R> h;
     constexpr bool CULL = (SF & SF_CULL) != 0;
-    if constexpr (PRIMARY) h = closest_hit_primary<R, TRACK, CULL>(S, *P, ro, rd);
-    else h = closest_hit<R, TRACK, CULL>(S, ro, rd, Num<R>::inf);
+    constexpr bool CHAIN = (SF & SF_CHAIN) != 0;
+    if constexpr (PRIMARY) h = closest_hit_primary<R, TRACK, CULL, CHAIN>(S, *P, ro, rd);
+    else h = closest_hit<R, TRACK, CULL, CHAIN>(S, ro, rd, Num<R>::inf);
     nd.hit = h.slot != kNone;
     nd.obj = h.obj;
     nd.t = h.t;

@@ -262,9 +262,19 @@ k_pack8(const R *__restrict__ rgb, uint32_t n_pix, uint32_t channels, uint8_t *_
 
 // ---- launchers --------------------------------------------------------------------------
 // One instantiation per combination of the feature bits that change code.
-constexpr uint32_t sf_variant(uint32_t k) { return (k & 7u) | ((k & 8u) ? SF_CULL : 0u); }
+// Scenes with groups share one general variant (reflection and refraction on, closest-hit shadow
+// rays), with and without the bounding-sphere tests.
+constexpr uint32_t sf_variant(uint32_t k)
+{
+    return k >= 16u ? (SF_REFLECTIVE | SF_TRANSPARENT | SF_CHAIN | ((k & 1u) ? SF_CULL : 0u))
+                    : ((k & 7u) | ((k & 8u) ? SF_CULL : 0u));
+}
+constexpr uint32_t sf_case(uint32_t sf)
+{
+    return (sf & SF_CHAIN) ? (16u | ((sf & SF_CULL) ? 1u : 0u)) : ((sf & 7u) | ((sf & SF_CULL) ? 8u : 0u));
+}
 #define RTX_SF_SWITCH(sf, CALL)                                                \
-    switch (((sf) & 7u) | (((sf) & SF_CULL) ? 8u : 0u)) {                      \
+    switch (sf_case(sf)) {                                                     \
     case 0u: CALL(sf_variant(0u)); break;                                      \
     case 1u: CALL(sf_variant(1u)); break;                                      \
     case 2u: CALL(sf_variant(2u)); break;                                      \
@@ -280,7 +290,9 @@ constexpr uint32_t sf_variant(uint32_t k) { return (k & 7u) | ((k & 8u) ? SF_CUL
     case 12u: CALL(sf_variant(12u)); break;                                    \
     case 13u: CALL(sf_variant(13u)); break;                                    \
     case 14u: CALL(sf_variant(14u)); break;                                    \
-    default: CALL(sf_variant(15u)); break;                                     \
+    case 15u: CALL(sf_variant(15u)); break;                                    \
+    case 16u: CALL(sf_variant(16u)); break;                                    \
+    default: CALL(sf_variant(17u)); break;                                     \
     }
 
 template <typename R>

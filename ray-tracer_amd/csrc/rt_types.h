@@ -19,6 +19,7 @@ enum : uint32_t {
     SF_ALL_CAST = 4u,     // every object casts a shadow: shadow rays may stop at any hit
     SF_PATTERN = 8u,      // some object carries a non-solid pattern
     SF_CULL = 16u,        // enough bounded objects that testing their bounding spheres first pays
+    SF_CHAIN = 32u,       // some object sits inside a Group
 };
 
 // ---- intersection tables -------------------------------------------------------------
@@ -44,6 +45,20 @@ struct alignas(sizeof(R) * 4) CappedRec {
     R ymin, ymax;
     uint32_t closed;
     uint32_t pad[(2 * sizeof(R) - 4) / 4];
+};
+
+// Object inside Groups (src/shapes/groups.rs:68-84): the ray is taken through the inverse of
+// every enclosing group, outermost first, one transform per level as the reference does (the
+// matrices are not pre-multiplied: that would round differently), then through the inverse of
+// the child as it was added.  Such objects are rare and come last in slot order; the shape is
+// a field, not a table.
+constexpr uint32_t kMaxChain = 3;  // nesting depth of groups
+template <typename R>
+struct alignas(sizeof(R) * 4) ChainRec {
+    R m[kMaxChain + 1][12];  // depth group inverses, then the child's own: rows 0..2 each
+    R ymin, ymax;
+    uint32_t type, closed, depth;
+    uint32_t pad[sizeof(R) == 8 ? 1 : 3];
 };
 
 // Bounding sphere of one object in world space, by slot.  r = +inf for planes, cones and
@@ -133,6 +148,7 @@ struct SceneDev {
     const XformRec<R> *cub;
     const CappedRec<R> *cyl;
     const CappedRec<R> *con;
+    const ChainRec<R> *chn;    // objects inside groups: slots n - n_chn .. n - 1
     const BoundRec<R> *bnd;    // by slot
     const BoundRec<R> *cl;     // cluster spheres; those of shape s start at cl_off[s]
     const BoundRec<R> *grp;    // group spheres; those of shape s start at grp_off[s]
@@ -143,7 +159,7 @@ struct SceneDev {
     uint32_t n_sph, n_pln, n_cub, n_cyl, n_con;
     uint32_t n;
     uint32_t flags;
-    uint32_t pad2;
+    uint32_t n_chn;
     R light_pos[3];
     R light_int[3];
 };

@@ -206,6 +206,7 @@ struct Tables {
     std::vector<XformRec<R>> sph, cub;
     std::vector<PlaneRec<R>> pln;
     std::vector<CappedRec<R>> cyl, con;
+    std::vector<ChainRec<R>> chn;
     std::vector<BoundRec<R>> bnd, cl, grp;
     uint32_t cl_off[5] = { 0, 0, 0, 0, 0 }, grp_off[5] = { 0, 0, 0, 0, 0 };
     std::vector<uint32_t> slot_obj;
@@ -224,6 +225,10 @@ std::vector<Bound> scene_bounds(const rtx_scene_desc *d, uint32_t *n_bounded)
     *n_bounded = 0;
     for (uint32_t i = 0; i < d->n_objects; ++i) {
         bounding_sphere(d, i, b[i].c, &b[i].r);
+        if (d->chain_depth && d->chain_depth[i]) {  // its cached inverse is not the one the ray goes through
+            b[i].c[0] = b[i].c[1] = b[i].c[2] = 0.0;
+            b[i].r = std::numeric_limits<double>::infinity();
+        }
         if (std::isfinite(b[i].r)) ++*n_bounded;
     }
     return b;
@@ -261,7 +266,8 @@ std::vector<uint32_t> table_order(const rtx_scene_desc *d, const std::vector<Bou
 {
     std::vector<uint32_t> idx, unbounded;
     for (uint32_t i = 0; i < d->n_objects; ++i)
-        if (d->shape_type[i] == shape) (!cull || std::isfinite(bounds[i].r) ? idx : unbounded).push_back(i);
+        if (d->shape_type[i] == shape && !(d->chain_depth && d->chain_depth[i]))
+            (!cull || std::isfinite(bounds[i].r) ? idx : unbounded).push_back(i);
     if (!cull) return idx;
     kd_order(idx, 0, idx.size(), bounds);
     idx.insert(idx.end(), unbounded.begin(), unbounded.end());
@@ -467,6 +473,25 @@ void fill_tables(const rtx_scene_desc *d, const std::vector<uint8_t> &container,
             }
         }
     }
+    // objects inside groups: last in slot order, World order among themselves
+    for (uint32_t i = 0; d->chain_depth && i < n; ++i) {
+        const uint32_t depth = d->chain_depth[i];
+        if (!depth) continue;
+        ChainRec<R> r;
+        std::memset(&r, 0, sizeof r);
+        for (uint32_t k = 0; k <= depth; ++k) {
+            const double *m = d->chain_inverse + ((size_t)d->chain_first[i] + k) * 16;
+            for (int e = 0; e < 12; ++e) r.m[k][e] = (R)m[e];
+        }
+        r.ymin = (R)d->ymin[i];
+        r.ymax = (R)d->ymax[i];
+        r.type = d->shape_type[i];
+        r.closed = d->closed[i] ? 1u : 0u;
+        r.depth = depth;
+        t.chn.push_back(r);
+        t.slot_obj.push_back(i);
+        t.bnd.push_back(store(bounds[i].c, bounds[i].r));
+    }
 }
 
 // One device allocation per scene and precision holding all tables back to back.
@@ -478,8 +503,9 @@ int upload_tables(const Tables<R> &t, uint32_t sf, const rtx_scene_desc *d, void
                  b_cub = pad(t.cub.size() * sizeof(XformRec<R>)), b_cyl = pad(t.cyl.size() * sizeof(CappedRec<R>)),
                  b_con = pad(t.con.size() * sizeof(CappedRec<R>)), b_slot = pad(t.slot_obj.size() * sizeof(uint32_t)),
                  b_cold = pad(t.cold.size() * sizeof(ColdRec<R>)), b_bnd = pad(t.bnd.size() * sizeof(BoundRec<R>)),
-                 b_cl = pad(t.cl.size() * sizeof(BoundRec<R>)), b_grp = pad(t.grp.size() * sizeof(BoundRec<R>));
-    const size_t total = b_sph + b_pln + b_cub + b_cyl + b_con + b_slot + b_cold + b_bnd + b_cl + b_grp + 256;
+                 b_cl = pad(t.cl.size() * sizeof(BoundRec<R>)), b_grp = pad(t.grp.size() * sizeof(BoundRec<R>)),
+                 b_chn = pad(t.chn.size() * sizeof(ChainRec<R>));
+    const size_t total = b_sph + b_pln + b_cub + b_cyl + b_con + b_slot + b_cold + b_bnd + b_cl + b_grp + b_chn + 256;
     std::vector<char> host(total, 0);
     size_t off = 0;
     auto put = [&](const void *src, size_t bytes, size_t padded) {
@@ -498,6 +524,7 @@ int upload_tables(const Tables<R> &t, uint32_t sf, const rtx_scene_desc *d, void
     const size_t o_bnd = put(t.bnd.data(), t.bnd.size() * sizeof(BoundRec<R>), b_bnd);
     const size_t o_cl = put(t.cl.data(), t.cl.size() * sizeof(BoundRec<R>), b_cl);
     const size_t o_grp = put(t.grp.data(), t.grp.size() * sizeof(BoundRec<R>), b_grp);
+    const size_t o_chn = put(t.chn.data(), t.chn.size() * sizeof(ChainRec<R>), b_chn);
     HIP_TRY(hipMalloc(blob, total));
     HIP_TRY(hipMemcpy(*blob, host.data(), total, hipMemcpyHostToDevice));
     char *base = (char *)*blob;
@@ -512,6 +539,8 @@ int upload_tables(const Tables<R> &t, uint32_t sf, const rtx_scene_desc *d, void
     dev->bnd = (const BoundRec<R> *)(base + o_bnd);
     dev->cl = (const BoundRec<R> *)(base + o_cl);
     dev->grp = (const BoundRec<R> *)(base + o_grp);
+    dev->chn = (const ChainRec<R> *)(base + o_chn);
+    dev->n_chn = (uint32_t)t.chn.size();
     for (int k = 0; k < 5; ++k) {
         dev->cl_off[k] = t.cl_off[k];
         dev->grp_off[k] = t.grp_off[k];
@@ -986,6 +1015,15 @@ int rtx_scene_upload(rtx_context *ctx, const rtx_scene_desc *d, rtx_scene **out)
         for (int k = 0; k < 16; ++k)
             if (!std::isfinite(d->inverse[(size_t)i * 16 + k]) || !std::isfinite(d->inverse_transposed[(size_t)i * 16 + k]))
                 return fail(RTX_ERR_INVALID, "object %u: transform is not finite", i);
+        if (d->chain_depth && d->chain_depth[i]) {
+            if (d->chain_depth[i] > kMaxChain)
+                return fail(RTX_ERR_INVALID, "object %u sits %u groups deep; at most %u levels are supported", i, d->chain_depth[i],
+                            kMaxChain);
+            if (!d->chain_first || !d->chain_inverse) return fail(RTX_ERR_INVALID, "chain_depth without chain_first / chain_inverse");
+            for (uint32_t k = 0; k < 16u * (d->chain_depth[i] + 1u); ++k)
+                if (!std::isfinite(d->chain_inverse[(size_t)d->chain_first[i] * 16 + k]))
+                    return fail(RTX_ERR_INVALID, "object %u: a group transform is not finite", i);
+        }
     }
     // Refraction containers (src/scenes/world.rs:253-285) find and remove objects by value
     // equality, so k objects that compare equal toggle one list entry k times per shared t:
@@ -1010,6 +1048,7 @@ int rtx_scene_upload(rtx_context *ctx, const rtx_scene_desc *d, rtx_scene **out)
         if (d->transparency[i] != 0.0) sf |= SF_TRANSPARENT;
         if (!d->casts_shadow[i]) sf &= ~SF_ALL_CAST;
         if (d->pattern_type[i] != RTX_SOLID) sf |= SF_PATTERN;
+        if (d->chain_depth && d->chain_depth[i]) sf |= SF_CHAIN;
     }
     DeviceGuard guard(ctx->device);
     if (!guard.ok) return fail(RTX_ERR_DEVICE, "hipSetDevice(%d) failed", ctx->device);

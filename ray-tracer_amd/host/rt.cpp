@@ -350,6 +350,42 @@ bool Object::operator==(const Object &o) const
            shape == o.shape && list_ == o.list_;
 }
 
+// ---- groups ----------------------------------------------------------------------------------------
+void Group::add_object(const Object &o)
+{
+    ObjectHolder h;
+    h.object = o;
+    group_.push_back(h);
+}
+void Group::add_group(const Group &g)
+{
+    ObjectHolder h;
+    h.is_group = true;
+    h.group = std::make_shared<const Group>(g);
+    group_.push_back(h);
+}
+// groups.rs:88-92
+void Group::set_transform(const Matrix4 &m)
+{
+    transform_ = m;
+    inverse_ = m.invert();
+    inverse_t_ = inverse_.transpose();
+}
+// groups.rs:94-97
+void Group::set_transformation_list(size_t index, double x)
+{
+    if (index >= 15) throw Panic("index out of bounds: the len is 15 but the index is " + std::to_string(index));
+    list_[index] = x;
+    update_transform();
+}
+// traits.rs:8-33
+void Group::update_transform()
+{
+    const auto &l = list_;
+    set_transform(translation(l[0], l[1], l[2]) * scaling(l[3], l[4], l[5]) * rotation_x(l[6]) * rotation_y(l[7]) *
+                  rotation_z(l[8]) * shearing(l[9], l[10], l[11], l[12], l[13], l[14]));
+}
+
 namespace spheres {
 Object new_() { return Object(Shape{ ShapeKind::Sphere, 0, 0, false }); }
 // spheres.rs:7-19
@@ -443,10 +479,42 @@ rtx_scene_desc FlatScene::desc() const
     d.pattern_color1 = pattern_color1.data();
     d.pattern_color2 = pattern_color2.data();
     d.eq_class = eq_class.empty() ? nullptr : eq_class.data();
+    d.chain_depth = chain_depth.empty() ? nullptr : chain_depth.data();
+    d.chain_first = chain_first.empty() ? nullptr : chain_first.data();
+    d.chain_inverse = chain_inverse.empty() ? nullptr : chain_inverse.data();
     d.n_lights = (uint32_t)(light_position.size() / 3);
     d.light_position = light_position.data();
     d.light_intensity = light_intensity.data();
     return d;
+}
+
+void World::add_leaves(const Group &g, std::vector<Matrix4> &inverses, std::vector<const std::array<double, 15> *> &lists)
+{
+    inverses.push_back(g.get_inverse_transform());
+    lists.push_back(&g.transformation_list_all());
+    for (const ObjectHolder &h : g.elements()) {
+        if (h.is_group) {
+            add_leaves(*h.group, inverses, lists);
+            continue;
+        }
+        Object merged = h.object;
+        for (size_t d = lists.size(); d-- > 0;) merged.combine_transforms(*lists[d]);
+        objects_.push_back(merged);
+        Chain c;
+        c.inverses = inverses;
+        c.inverses.push_back(h.object.get_inverse_transform());
+        chains_.push_back(c);
+    }
+    inverses.pop_back();
+    lists.pop_back();
+}
+size_t World::add_group(const Group &g)
+{
+    const size_t first = objects_.size();
+    std::vector<Matrix4> inverses;
+    std::vector<const std::array<double, 15> *> lists;
+    add_leaves(g, inverses, lists);
+    return first;
 }
 
 FlatScene World::flatten() const
@@ -492,6 +560,19 @@ FlatScene World::flatten() const
                     f.eq_class[i] = f.eq_class[j];
                     break;
                 }
+        }
+    }
+    bool any_chain = false;
+    for (const Chain &c : chains_) any_chain = any_chain || !c.inverses.empty();
+    if (any_chain) {
+        for (size_t i = 0; i < n; ++i) {
+            const Chain &c = chains_[i];
+            f.chain_depth.push_back(c.inverses.empty() ? 0 : (uint8_t)std::min<size_t>(255, c.inverses.size() - 1));
+            f.chain_first.push_back((uint32_t)(f.chain_inverse.size() / 16));
+            for (const Matrix4 &m : c.inverses) {
+                f.chain_inverse.resize(f.chain_inverse.size() + 16);
+                m.store(&f.chain_inverse[f.chain_inverse.size() - 16]);
+            }
         }
     }
     for (const Light &l : lights_) {

@@ -9,6 +9,7 @@
 #pragma once
 
 #include <array>
+#include <memory>
 #include <atomic>
 #include <cstdint>
 #include <stdexcept>
@@ -199,6 +200,47 @@ namespace cubes { Object new_(); }
 namespace cylinders { Object new_(double min, double max, bool closed); Object new_unbounded(); }
 namespace cones { Object new_(double min, double max, bool closed); Object new_unbounded(); }
 
+// ---- src/shapes/groups.rs, src/shapes/objectholders.rs ------------------------------------------
+class Group;
+// enum ObjectHolder { Object(Object), Group(Group) } (objectholders.rs:5-8)
+struct ObjectHolder {
+    bool is_group = false;
+    Object object{ Shape{} };
+    std::shared_ptr<const Group> group;  // value semantics: a holder never shares a mutable group
+};
+class Group {
+public:
+    Group() = default;  // Group::new_empty, groups.rs:30-43
+    void add_object(const Object &o);           // groups.rs:49-51
+    void add_group(const Group &g);             // groups.rs:53-55
+    const std::vector<ObjectHolder> &elements() const { return group_; }
+
+    // Transformable (src/shapes/traits.rs), as for Object
+    void set_transform(const Matrix4 &m);
+    void set_transformation_list(size_t index, double x);
+    void update_transform();
+    void translate_x(double v) { set_transformation_list(0, v); }
+    void translate_y(double v) { set_transformation_list(1, v); }
+    void translate_z(double v) { set_transformation_list(2, v); }
+    void scale_x(double v) { set_transformation_list(3, v != 0.0 ? v : EPSILON); }
+    void scale_y(double v) { set_transformation_list(4, v != 0.0 ? v : EPSILON); }
+    void scale_z(double v) { set_transformation_list(5, v != 0.0 ? v : EPSILON); }
+    void rotate_x(double v) { set_transformation_list(6, v); }
+    void rotate_y(double v) { set_transformation_list(7, v); }
+    void rotate_z(double v) { set_transformation_list(8, v); }
+    const Matrix4 &get_transform() const { return transform_; }
+    const Matrix4 &get_inverse_transform() const { return inverse_; }
+    const Matrix4 &get_inverse_transform_transposed() const { return inverse_t_; }
+    const std::array<double, 15> &transformation_list_all() const { return list_; }
+
+private:
+    std::vector<ObjectHolder> group_;
+    Matrix4 transform_ = Matrix4::identity();
+    Matrix4 inverse_ = Matrix4::identity();
+    Matrix4 inverse_t_ = Matrix4::identity();
+    std::array<double, 15> list_{ { 0, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0 } };
+};
+
 // ---- src/scenes/lights.rs -------------------------------------------------------------------
 struct Light {
     Tuple position;
@@ -227,6 +269,10 @@ struct FlatScene {
         reflective, transparency, refractive_index, pattern_inverse, pattern_color1, pattern_color2, light_position,
         light_intensity;
     std::vector<uint32_t> eq_class;
+    // objects inside groups (empty when the world has none): see rtx_scene_desc
+    std::vector<uint8_t> chain_depth;
+    std::vector<uint32_t> chain_first;
+    std::vector<double> chain_inverse;
     rtx_scene_desc desc() const;
 };
 
@@ -234,9 +280,21 @@ struct FlatScene {
 class World {
 public:
     World() = default;
-    World(std::vector<Object> objects, std::vector<Light> lights) : objects_(std::move(objects)), lights_(std::move(lights)) {}
+    World(std::vector<Object> objects, std::vector<Light> lights)
+        : objects_(std::move(objects)), chains_(objects_.size()), lights_(std::move(lights)) {}
     static World new_default();
-    void add_object(const Object &o) { objects_.push_back(o); }
+    void add_object(const Object &o) { objects_.push_back(o); chains_.emplace_back(); }
+    // World::add_group (world.rs:82-84).  The group's objects are appended to objects() depth
+    // first -- the order the nested stable sorts of Group::local_intersect (groups.rs:73-84) and
+    // intersect_world (world.rs:98-107) leave equal t in -- as the copies the reference returns in
+    // its Intersections: the child with every enclosing group's transformation list merged in
+    // (combine_transforms, traits.rs:35-44), innermost group first.  How the ray reaches the child
+    // is kept beside it (chain()).  Returns the index of the first such object.
+    size_t add_group(const Group &g);
+    struct Chain {
+        std::vector<Matrix4> inverses;  // enclosing groups, outermost first, then the child's own; empty for a plain object
+    };
+    const Chain &chain(size_t index) const { return chains_.at(index); }
     void add_light(const Light &l) { lights_.push_back(l); }
     std::vector<Object> &objects() { return objects_; }
     const std::vector<Object> &objects() const { return objects_; }
@@ -250,7 +308,9 @@ public:
     Color color_at(const Ray &ray, uint32_t remaining) const;
 
 private:
+    void add_leaves(const Group &g, std::vector<Matrix4> &inverses, std::vector<const std::array<double, 15> *> &lists);
     std::vector<Object> objects_;
+    std::vector<Chain> chains_;  // parallel to objects_
     std::vector<Light> lights_;
 };
 

@@ -160,6 +160,60 @@ int rt_world_add_object(rt_world *w, const rt_object *o)
     w->w.add_object(o->o);
     return (int)w->w.objects().size() - 1;
 }
+// ---- groups --------------------------------------------------------------------------------------
+struct rt_group {
+    Group g;
+};
+rt_group *rt_group_new(void) { return new rt_group; }
+void rt_group_free(rt_group *g) { delete g; }
+int rt_group_add_object(rt_group *g, const rt_object *o)
+{
+    g->g.add_object(o->o);
+    return (int)g->g.elements().size() - 1;
+}
+int rt_group_add_group(rt_group *g, const rt_group *child)
+{
+    g->g.add_group(child->g);
+    return (int)g->g.elements().size() - 1;
+}
+int rt_group_n_elements(const rt_group *g) { return (int)g->g.elements().size(); }
+int rt_group_set_transform(rt_group *g, const double *m16)
+{
+    return guarded([&] { g->g.set_transform(Matrix4::convert(m16)); });
+}
+int rt_group_set_transformation_list(rt_group *g, int index, double x)
+{
+    return guarded([&] { g->g.set_transformation_list((size_t)index, x); });
+}
+int rt_group_transform_op(rt_group *g, int slot, double x)
+{
+    return guarded([&] {
+        if (slot >= 3 && slot <= 5 && !(x != 0.0)) x = EPSILON;  // traits.rs:58-80
+        g->g.set_transformation_list((size_t)slot, x);
+    });
+}
+void rt_group_get_matrices(const rt_group *g, double *transform, double *inverse, double *inverse_t)
+{
+    if (transform) g->g.get_transform().store(transform);
+    if (inverse) g->g.get_inverse_transform().store(inverse);
+    if (inverse_t) g->g.get_inverse_transform_transposed().store(inverse_t);
+}
+int rt_world_add_group(rt_world *w, const rt_group *g)
+{
+    int first = -1;
+    const int rc = guarded([&] { first = (int)w->w.add_group(g->g); });
+    return rc ? -1 : first;
+}
+int rt_world_object_chain(const rt_world *w, int index, double *inverses16, int cap)
+{
+    if (index < 0 || index >= (int)w->w.objects().size()) return -1;
+    const World::Chain &c = w->w.chain((size_t)index);
+    if (c.inverses.empty()) return 0;
+    const int depth = (int)c.inverses.size() - 1;
+    for (int d = 0; d < depth && d < cap; ++d) c.inverses[(size_t)d].store(inverses16 + 16 * d);
+    return depth;
+}
+
 void rt_world_add_light(rt_world *w, const double *p, const double *i)
 {
     w->w.add_light(Light(point(p[0], p[1], p[2]), col3(i)));
@@ -244,6 +298,11 @@ int64_t rt_world_flat(const rt_world *w, int field, double *out, int64_t cap)
             v.insert(v.end(), { f.pattern_color1[i * 3], f.pattern_color1[i * 3 + 1], f.pattern_color1[i * 3 + 2],
                                 f.pattern_color2[i * 3], f.pattern_color2[i * 3 + 1], f.pattern_color2[i * 3 + 2] });
         break;
+    case RT_FLAT_CHAIN:
+        for (size_t i = 0; i < n; ++i)
+            v.insert(v.end(), { f.chain_depth.empty() ? 0.0 : (double)f.chain_depth[i], f.chain_first.empty() ? 0.0 : (double)f.chain_first[i] });
+        break;
+    case RT_FLAT_CHAIN_INVERSE: v = f.chain_inverse; break;
     default: return -1;
     }
     if (out)

@@ -74,6 +74,17 @@ class SceneAPI:
         f("object_get_matrices", None, [vp, _dp, _dp, _dp])
         f("object_get_pattern_inverse", None, [vp, _dp])
         f("object_equal", C.c_int, [vp, vp])
+        f("group_new", vp, [])
+        f("group_free", None, [vp])
+        f("group_add_object", C.c_int, [vp, vp])
+        f("group_add_group", C.c_int, [vp, vp])
+        f("group_n_elements", C.c_int, [vp])
+        f("group_set_transform", C.c_int, [vp, _dp])
+        f("group_set_transformation_list", C.c_int, [vp, C.c_int, d])
+        f("group_transform_op", C.c_int, [vp, C.c_int, d])
+        f("group_get_matrices", None, [vp, _dp, _dp, _dp])
+        f("world_add_group", C.c_int, [vp, vp])
+        f("world_object_chain", C.c_int, [vp, C.c_int, _dp, C.c_int])
         f("world_new", vp, [])
         f("world_default", vp, [])
         f("world_free", None, [vp])
@@ -183,6 +194,9 @@ class SceneAPI:
     def cone(self, ymin=-F64_MAX, ymax=F64_MAX, closed=False):
         return Object(self, self.object_new(CONE, ymin, ymax, int(closed)))
 
+    def group(self):
+        return Group(self, self.group_new())
+
     def world(self):
         return World(self, self.world_new())
 
@@ -291,6 +305,71 @@ class Object:
         return bool(self.api.object_equal(self.h, other.h))
 
 
+class Group:
+    """src/shapes/groups.rs `Group` with the `Transformable` helpers of src/shapes/traits.rs.
+    Adding an object or a group stores a copy, as moving the value does in Rust."""
+
+    def __init__(self, api, handle):
+        self.api = api
+        self.h = handle
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.api.group_free(self.h)
+            self.h = None
+
+    def add_object(self, obj):
+        self.api.group_add_object(self.h, obj.h)
+        return self
+
+    def add_group(self, group):
+        self.api.group_add_group(self.h, group.h)
+        return self
+
+    def __len__(self):
+        return self.api.group_n_elements(self.h)
+
+    def set_transform(self, m):
+        m = _vec(m, 16)
+        self.api.check(self.api.group_set_transform(self.h, _ptr(m)))
+        return self
+
+    def set_transformation_list(self, index, x):
+        self.api.check(self.api.group_set_transformation_list(self.h, index, x))
+        return self
+
+    def _op(self, slot, x):
+        self.api.check(self.api.group_transform_op(self.h, slot, float(x)))
+        return self
+
+    def translate_x(self, v): return self._op(0, v)
+    def translate_y(self, v): return self._op(1, v)
+    def translate_z(self, v): return self._op(2, v)
+    def scale_x(self, v): return self._op(3, v)
+    def scale_y(self, v): return self._op(4, v)
+    def scale_z(self, v): return self._op(5, v)
+    def rotate_x(self, v): return self._op(6, v)
+    def rotate_y(self, v): return self._op(7, v)
+    def rotate_z(self, v): return self._op(8, v)
+    def shear_xy(self, v): return self._op(9, v)
+    def shear_xz(self, v): return self._op(10, v)
+    def shear_yx(self, v): return self._op(11, v)
+    def shear_yz(self, v): return self._op(12, v)
+    def shear_zx(self, v): return self._op(13, v)
+    def shear_zy(self, v): return self._op(14, v)
+
+    def translate(self, x, y, z):
+        return self.translate_x(x).translate_y(y).translate_z(z)
+
+    def scale(self, x, y, z):
+        return self.scale_x(x).scale_y(y).scale_z(z)
+
+    def matrices(self):
+        t, i, it = np.empty(16), np.empty(16), np.empty(16)
+        self.api.group_get_matrices(self.h, _ptr(t), _ptr(i), _ptr(it))
+        return t.reshape(4, 4), i.reshape(4, 4), it.reshape(4, 4)
+
+
 class World:
     """src/scenes/world.rs `World`."""
 
@@ -305,6 +384,19 @@ class World:
 
     def add_object(self, obj):
         return self.api.world_add_object(self.h, obj.h)
+
+    def add_group(self, group):
+        """World::add_group: returns the index of the group's first object in the flattened list."""
+        first = self.api.world_add_group(self.h, group.h)
+        if first < 0:
+            raise Panic(self.api.last_panic().decode("utf-8", "replace"))
+        return first
+
+    def chain(self, index):
+        """Inverse transforms of the groups around object `index`, outermost first: (depth, 4, 4)."""
+        buf = np.zeros(16 * 16)
+        depth = self.api.world_object_chain(self.h, index, _ptr(buf), 16)
+        return buf[: 16 * max(depth, 0)].reshape(-1, 4, 4)
 
     def add_light(self, position, intensity=(1.0, 1.0, 1.0)):
         p, i = _vec(position, 3), _vec(intensity, 3)

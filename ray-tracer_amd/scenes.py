@@ -132,9 +132,44 @@ def random_scene(api, n_objects=10000, hsize=3840, vsize=2160, seed=0xC0FFEE):
     return w, cam
 
 
+def grouped_scene(api, hsize=160, vsize=90, nested=True):
+    """Objects inside Groups (src/shapes/groups.rs): a transformed group holding one of each shape,
+    a nested group two levels down, a child positioned with set_transform (which the merged copy
+    used for shading discards, src/shapes/traits.rs:35-44), next to plain objects."""
+    w = api.world()
+    w.add_object(api.plane().set_pattern(CHECKER3D, (0.9, 0.9, 0.9), (0.2, 0.2, 0.25)).set_reflective(0.2))
+    g = api.group().translate(0.5, 0.0, 1.0).rotate_y(0.4).scale(1.2, 1.2, 1.2)
+    g.add_object(api.sphere().translate(-1.5, 1.0, 0.0).set_color(0.9, 0.3, 0.2).set_reflective(0.3))
+    g.add_object(api.cube().translate(1.2, 0.5, 0.3).scale(0.5, 0.5, 0.5).rotate_y(0.3)
+                 .set_pattern(STRIPE, (0.2, 0.6, 0.9), (0.9, 0.9, 0.3)).set_pattern_transform(api.m_scaling(0.3, 0.3, 0.3)))
+    g.add_object(api.cylinder(0.0, 1.2, True).translate(0.0, 0.0, -1.5).scale(0.4, 1.0, 0.4).set_color(0.3, 0.8, 0.4))
+    g.add_object(api.cone(-1.0, 0.0, True).translate(2.4, 1.0, -0.8).scale(0.5, 1.0, 0.5)
+                 .set_pattern(GRADIENT, (0.9, 0.2, 0.6), (0.2, 0.9, 0.9)))
+    if nested:
+        inner = api.group().translate(0.0, 1.6, 0.0).rotate_z(0.3).shear_xy(0.15)
+        inner.add_object(api.glass().scale(0.6, 0.6, 0.6))
+        inner.add_object(api.sphere().scale(0.25, 0.25, 0.25).set_color(0.1, 0.1, 0.9))
+        deepest = api.group().translate_x(1.1).scale(0.5, 0.5, 0.5)
+        deepest.add_object(api.cube().rotate_x(0.5).set_color(0.9, 0.8, 0.1).set_transparency(0.4).set_refractive_index(1.3))
+        inner.add_group(deepest)
+        g.add_group(inner)
+    moved = api.sphere().set_color(0.8, 0.8, 0.8)
+    moved.set_transform(api.m_chain(api.m_translation(-2.8, 0.5, 1.5), api.m_scaling(0.5, 0.5, 0.5)))
+    g.add_object(moved)
+    w.add_group(g)
+    w.add_object(api.sphere().translate(-3.0, 0.7, -1.0).scale(0.7, 0.7, 0.7).set_color(0.6, 0.2, 0.7))
+    solo = api.group()  # an untransformed group: merged lists equal the child's own
+    solo.add_object(api.cube().translate(3.2, 0.4, 2.0).scale(0.4, 0.4, 0.4).set_reflective(0.5))
+    w.add_group(solo)
+    w.add_light((-6.0, 8.0, -7.0))
+    cam = _camera(api, hsize, vsize, math.pi / 3.0, (0.0, 3.0, -8.0), (0.0, 1.0, 0.0))
+    return w, cam
+
+
 SCENES = {
     "default": default_scene,
     "spheres_on_plane": spheres_on_plane,
     "glass": glass_scene,
     "random": random_scene,
+    "grouped": grouped_scene,
 }

@@ -238,6 +238,31 @@ def parallel_render(camera, world, depth=5, n_threads=None, counters=None):
     return full
 
 
+_group_intersect = _bind("orc_group_intersect", C.c_int, [_vp, _dp, _dp, _vp, C.c_int])
+_object_sizeof = _bind("orc_object_sizeof", C.c_size_t, [])
+_object_equal_raw = _bind("orc_object_equal", C.c_int, [_vp, _vp])
+
+
+def group_intersect(group, ray, cap=256):
+    """Group::intersect as the reference writes it (recursive, every level sorts):
+    (t values, list of raw copies of the Objects the Intersections carry).  The copies are opaque
+    byte blocks; compare them with object_equals_raw."""
+    r = _a(ray, 6)
+    ts = np.empty(cap)
+    size = _object_sizeof()
+    buf = C.create_string_buffer(size * cap)
+    n = _group_intersect(group.h, _p(r), _p(ts), C.cast(buf, _vp), cap)
+    if n < 0:
+        raise scene_api.Panic(api.last_panic().decode())
+    base = C.addressof(buf)
+    return ts[:n].copy(), [(buf, base + i * size) for i in range(n)]
+
+
+def object_equals_raw(raw, obj):
+    """derived PartialEq between a copy returned by group_intersect and an Object wrapper"""
+    return bool(_object_equal_raw(_vp(raw[1]), obj.h))
+
+
 def quantize_u8(rgb):
     a = np.ascontiguousarray(rgb, dtype=np.float64)
     out = np.empty(a.shape, dtype=np.uint8)
