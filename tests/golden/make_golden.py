@@ -27,6 +27,7 @@ CASES = {
     "glass_64x36_d5": ("glass", dict(hsize=64, vsize=36), 5),
     "glass_64x36_d2": ("glass", dict(hsize=64, vsize=36), 2),
     "random60_48x27_d5": ("random", dict(n_objects=60, hsize=48, vsize=27), 5),
+    "grouped_80x45_d5": ("grouped", dict(hsize=80, vsize=45), 5),
 }
 
 
