@@ -146,6 +146,17 @@ struct SlotLease {
     }
 };
 
+// An earlier call may have returned with work still in flight that uses this slot's scratch
+// memory, possibly on another stream: whatever `stream` runs next waits for it on the device.
+int slot_order_after_pending(Slot *slot, hipStream_t stream)
+{
+    if (slot->pending) {
+        HIP_TRY(hipStreamWaitEvent(stream, slot->done, 0));
+        slot->pending = false;
+    }
+    return RTX_OK;
+}
+
 int grow(void **ptr, size_t *have, size_t need)
 {
     if (need <= *have) return RTX_OK;
@@ -822,11 +833,8 @@ int render_impl(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_desc 
     if (stats) std::memset(stats, 0, sizeof *stats);
     if (n_pix == 0) return RTX_OK;
     hipStream_t stream = user_stream ? user_stream : slot->stream;
-    // an earlier asynchronous call may still be using this slot's scratch on another stream
-    if (slot->pending) {
-        HIP_TRY(hipStreamWaitEvent(stream, slot->done, 0));
-        slot->pending = false;
-    }
+    rc = slot_order_after_pending(slot, stream);
+    if (rc) return rc;
     R *d_fb = (R *)dev_out;
     if (!d_fb) {
         rc = grow(&slot->fb, &slot->fb_bytes, (size_t)(n_pix * 3 * sizeof(R)));
@@ -884,6 +892,8 @@ int trace_impl(rtx_context *ctx, const rtx_scene *scene, const double *rays, siz
     rc = grow(&slot->fb, &slot->fb_bytes, n * 3 * sizeof(R));
     if (rc) return rc;
     hipStream_t stream = slot->stream;
+    rc = slot_order_after_pending(slot, stream);
+    if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(slot->aux, rays, ray_bytes, hipMemcpyHostToDevice, stream));
     uint32_t n_chunks = 0, n_launch = 0;
     rc = enqueue_frame<R>(ctx, scene, slot, stream, nullptr, (const double *)slot->aux, 0, n, max_depth, (R *)slot->fb,
@@ -1174,6 +1184,8 @@ int rtx_probe_rays(rtx_context *ctx, const rtx_scene *scene, const double *rays,
     const size_t ray_pad = (ray_bytes + 255) & ~(size_t)255;
     rc = grow(&slot->aux, &slot->aux_bytes, ray_pad + n * sizeof(rtx_probe));
     if (rc) return rc;
+    rc = slot_order_after_pending(slot, slot->stream);
+    if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(slot->aux, rays, ray_bytes, hipMemcpyHostToDevice, slot->stream));
     rtx_probe *d_out = (rtx_probe *)((char *)slot->aux + ray_pad);
     HIP_TRY(launch_probe(scene->sf, grid_for(ctx, n), slot->stream, scene->dev64, (const double *)slot->aux, (uint32_t)n, d_out));
@@ -1197,6 +1209,8 @@ int rtx_generate_rays(rtx_context *ctx, const rtx_camera_desc *camera, uint64_t 
     if (rc) return rc;
     Slot *slot = lease.slot;
     rc = grow(&slot->aux, &slot->aux_bytes, n * 6 * sizeof(double));
+    if (rc) return rc;
+    rc = slot_order_after_pending(slot, slot->stream);
     if (rc) return rc;
     const CameraDev<double> cd = make_camera<double>(camera);
     HIP_TRY(Launch<double>::raygen(grid_for(ctx, n), slot->stream, cd, (uint32_t)first_pixel, (uint32_t)n, (double *)slot->aux));
