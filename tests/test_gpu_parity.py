@@ -419,6 +419,56 @@ def test_concurrent_renders_share_a_context(orc, rta):
         assert np.abs(img - expect_prev).max() <= 1e-12
 
 
+def test_calls_after_an_asynchronous_render_are_ordered(orc, rta):
+    """rtx_render_device returns with its kernels in flight on the caller's stream; a batch call
+    that follows at once reuses the same scratch memory on another stream and must wait for them
+    on the device.  Both results must be what they are in isolation."""
+    import ctypes as C
+    from ray_tracer_amd import scenes
+    # the HIP runtime librtx.so already brought in (a second copy of it would see no device)
+    with open("/proc/self/maps") as f:
+        paths = sorted({line.split()[-1] for line in f if "libamdhip64.so" in line})
+    assert paths, "librtx.so did not load a HIP runtime"
+    hip = C.CDLL(paths[0])
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipFree.argtypes = [C.c_void_p]
+    hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    ctx = rta.Context()
+    w, cam = scenes.glass_scene(rta.api, 640, 360)
+    scene = rta.Scene(ctx, rta.flatten(w))
+    cd = rta.camera_desc(cam)
+    want = np.empty((360, 640, 3))
+    rta._check(rta.rtx_render(ctx.h, scene.h, cd, 5, rta.F64, 0, 360, want.ctypes.data, want.nbytes, None, None, None))
+    rays = np.ascontiguousarray(np.array([rta.ray_for_pixel(cam, x, 200) for x in range(0, 640, 5)]))
+    want_cols = np.empty((len(rays), 3))
+    rta._check(rta.rtx_trace_rays(ctx.h, scene.h, rays.ctypes.data_as(rta._dp), len(rays), 5, rta.F64,
+                                  want_cols.ctypes.data_as(rta._dp), None))
+    d_tile, stream = C.c_void_p(), C.c_void_p()
+    assert hip.hipMalloc(C.byref(d_tile), want.nbytes) == 0
+    assert hip.hipStreamCreate(C.byref(stream)) == 0
+    try:
+        for _ in range(5):
+            assert hip.hipMemset(d_tile, 0, want.nbytes) == 0
+            rta.render_device(ctx, scene, cd, 5, rta.F64, 0, 360, d_tile.value, want.nbytes, stream.value)
+            cols = np.empty((len(rays), 3))
+            rta._check(rta.rtx_trace_rays(ctx.h, scene.h, rays.ctypes.data_as(rta._dp), len(rays), 5, rta.F64,
+                                          cols.ctypes.data_as(rta._dp), None))
+            assert hip.hipStreamSynchronize(stream) == 0
+            got = np.empty_like(want)
+            assert hip.hipMemcpy(got.ctypes.data, d_tile, want.nbytes, 2) == 0  # hipMemcpyDeviceToHost
+            assert np.abs(cols - want_cols).max() <= 1e-12
+            assert np.abs(got - want).max() <= 1e-12
+    finally:
+        hip.hipStreamDestroy(stream)
+        hip.hipFree(d_tile)
+        scene.close()
+        ctx.close()
+
+
 def test_full_size_frame_properties(orc, rta):
     """BASELINE size (3840x2160, default world): a random sample of pixels against the oracle's
     color_at for the same primary rays, the ray counters against geometry, and the frame
