@@ -21,6 +21,31 @@ LIB_PATH = os.environ.get("RTX_LIB") or os.path.join(_HERE, "lib", "librtx.so")
 if not os.path.exists(LIB_PATH):
     raise ImportError("%s is missing: build it with ./build.sh (python -c 'import __graft_entry__ as g; g.build()')"
                       % LIB_PATH)
+
+
+def _share_hip_runtime_with_torch():
+    """One process must hold ONE HIP runtime: a second copy opens no device ("No HIP GPUs are
+    available").  PyTorch ships its own libamdhip64.so and asks for it by a name that does not
+    match the SONAME librtx.so links against, so loading librtx.so first and importing torch later
+    would bring in two.  If a PyTorch install is present and not yet imported, its copy is loaded
+    here, globally, before librtx.so: same SONAME, so librtx.so binds to it, and a later
+    `import torch` finds it already mapped."""
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except (ImportError, OSError, ValueError):
+        pass
+
+
+_share_hip_runtime_with_torch()
 lib = C.CDLL(LIB_PATH)
 
 _dp = C.POINTER(C.c_double)
