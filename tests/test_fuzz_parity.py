@@ -1,0 +1,103 @@
+"""Randomised worlds, GPU against oracle.  Every world mixes all five shapes, all six patterns,
+random materials (reflective, transparent, non-shadow-casting), transforms given through the
+transformation list (with shears) or as matrices, value-identical twins, and optionally nested
+groups; cameras are random too.  Frames must agree to 1e-9 with equal ray counters, and the
+per-ray intermediate results must be bit-identical."""
+import math
+
+import numpy as np
+import pytest
+
+TOL = 1e-9
+
+
+def build_world(api, seed, groups):
+    from ray_tracer_amd.scene_api import CHECKER3D, GRADIENT, RING, SOLID, STRIPE, TEST
+    rng = np.random.default_rng(seed)
+    u = rng.uniform
+
+    def random_object():
+        kind = int(rng.integers(0, 5))
+        if kind == 0:
+            o = api.sphere()
+        elif kind == 1:
+            o = api.cube()
+        elif kind == 2:
+            lo = u(-1.5, 0.0)
+            o = api.cylinder(lo, lo + u(0.3, 2.0), bool(rng.integers(0, 2))) if rng.random() < 0.8 else api.cylinder()
+        elif kind == 3:
+            lo = u(-1.5, 0.0)
+            o = api.cone(lo, lo + u(0.3, 2.0), bool(rng.integers(0, 2))) if rng.random() < 0.8 else api.cone()
+        else:
+            o = api.glass() if rng.random() < 0.5 else api.sphere()
+        if rng.random() < 0.25:
+            m = api.m_chain(api.m_translation(u(-4, 4), u(0, 3), u(-3, 5)), api.m_rotation_y(u(0, 6.28)),
+                            api.m_scaling(u(0.3, 1.4), u(0.3, 1.4), u(0.3, 1.4)))
+            o.set_transform(m)
+        else:
+            o.translate(u(-4, 4), u(0, 3), u(-3, 5)).scale(u(0.3, 1.4), u(0.3, 1.4), u(0.3, 1.4))
+            o.rotate_x(u(0, 6.28)).rotate_y(u(0, 6.28)).rotate_z(u(0, 6.28))
+            if rng.random() < 0.3:
+                o.shear_xy(u(-0.4, 0.4)).shear_zx(u(-0.4, 0.4))
+        o.set_color(u(0, 1), u(0, 1), u(0, 1)).set_ambient(u(0, 0.3)).set_diffuse(u(0.2, 1)).set_specular(u(0, 1))
+        o.set_shininess(u(5, 300))
+        if rng.random() < 0.35:
+            o.set_reflective(u(0.1, 0.9))
+        if rng.random() < 0.3:
+            o.set_transparency(u(0.2, 1.0)).set_refractive_index(u(1.0, 2.4))
+        if rng.random() < 0.2:
+            o.set_casts_shadow(False)
+        p = int(rng.integers(0, 7))
+        if p < 6 and p != SOLID:
+            o.set_pattern([SOLID, STRIPE, GRADIENT, RING, CHECKER3D, TEST][p], (u(0, 1), u(0, 1), u(0, 1)), (u(0, 1), u(0, 1), u(0, 1)))
+            o.set_pattern_transform(api.m_chain(api.m_rotation_z(u(0, 3)), api.m_scaling(u(0.1, 1), u(0.1, 1), u(0.1, 1))))
+        return o
+
+    w = api.world()
+    floor = api.plane().set_pattern(CHECKER3D, (0.9, 0.9, 0.9), (0.1, 0.1, 0.1))
+    if rng.random() < 0.5:
+        floor.set_reflective(u(0.1, 0.6))
+    w.add_object(floor)
+    n = int(rng.integers(4, 14))
+    for i in range(n):
+        o = random_object()
+        w.add_object(o)
+        if rng.random() < 0.15:
+            w.add_object(o.clone())  # a twin that compares equal: aliases in the refraction container list
+    if groups:
+        g = api.group().translate(u(-2, 2), u(0, 1), u(-1, 2)).rotate_y(u(0, 6.28)).scale(u(0.6, 1.3), u(0.6, 1.3), u(0.6, 1.3))
+        for _ in range(int(rng.integers(1, 4))):
+            g.add_object(random_object())
+        inner = api.group().translate(u(-1, 1), u(0, 1), u(-1, 1)).rotate_x(u(0, 6.28))
+        if rng.random() < 0.5:
+            inner.shear_yx(u(-0.3, 0.3))
+        for _ in range(int(rng.integers(1, 3))):
+            inner.add_object(random_object())
+        g.add_group(inner)
+        w.add_group(g)
+        w.add_object(random_object())
+    w.add_light((u(-8, 8), u(4, 10), u(-9, -3)), (u(0.5, 1), u(0.5, 1), u(0.5, 1)))
+    cam = api.camera(int(rng.integers(40, 72)), int(rng.integers(28, 48)), u(0.6, 1.4))
+    cam.set_view((u(-3, 3), u(1, 5), u(-9, -5)), (u(-1, 1), u(0, 2), u(0, 2)), (u(-0.2, 0.2), 1.0, u(-0.2, 0.2)))
+    return w, cam
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(48))
+def test_random_worlds_match_the_oracle(orc, rta, seed):
+    import test_gpu_parity as tg
+    groups = seed % 2 == 1
+    depth = [5, 5, 2, 5, 1, 5, 0, 3][seed % 8]
+    got, want, gstats, cnt = tg.frame_pair(orc, rta, build_world, depth=depth, seed=1000 + seed, groups=groups)
+    finite = np.isfinite(want)
+    assert np.array_equal(finite, np.isfinite(got))
+    assert np.abs(got[finite] - want[finite]).max() <= TOL
+    assert gstats["color_rays"] == cnt[0] and gstats["shadow_rays"] == cnt[1]
+    rng = np.random.default_rng(seed)
+    o = rng.uniform(-5, 5, size=(600, 3))
+    o[:, 2] = rng.uniform(-9, -4, size=600)
+    d = rng.uniform(-3, 3, size=(600, 3)) - o
+    d[:, 1] += 1.0
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    n_hit = tg.assert_probe_matches(orc, rta, build_world, np.concatenate([o, d], axis=1), seed=1000 + seed, groups=groups)
+    assert n_hit > 100
