@@ -11,7 +11,7 @@ import pytest
 TOL = 1e-9
 
 
-def build_world(api, seed, groups):
+def build_world(api, seed, groups, res_scale=1):
     from ray_tracer_amd.scene_api import CHECKER3D, GRADIENT, RING, SOLID, STRIPE, TEST
     rng = np.random.default_rng(seed)
     u = rng.uniform
@@ -77,7 +77,7 @@ def build_world(api, seed, groups):
         w.add_group(g)
         w.add_object(random_object())
     w.add_light((u(-8, 8), u(4, 10), u(-9, -3)), (u(0.5, 1), u(0.5, 1), u(0.5, 1)))
-    cam = api.camera(int(rng.integers(40, 72)), int(rng.integers(28, 48)), u(0.6, 1.4))
+    cam = api.camera(int(rng.integers(40, 72)) * res_scale, int(rng.integers(28, 48)) * res_scale, u(0.6, 1.4))
     cam.set_view((u(-3, 3), u(1, 5), u(-9, -5)), (u(-1, 1), u(0, 2), u(0, 2)), (u(-0.2, 0.2), 1.0, u(-0.2, 0.2)))
     return w, cam
 
