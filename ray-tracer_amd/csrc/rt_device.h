@@ -351,21 +351,33 @@ RT_DEV void walk_table(const Rec *recs, uint32_t n, uint32_t slot0, uint32_t clu
                        Body &&body)
 {
     if constexpr (Keep::clustered) {
+        // Spheres are fetched four at a time: a walk is a chain of scalar loads, each of which
+        // costs its full latency when the wave is alone on its SIMD (secondary rays), and one
+        // wait then covers four of them.  kCluster is a multiple of 4; the tables are padded.
+        static_assert(kCluster % 4 == 0, "spheres are fetched in fours");
         const uint32_t n_cl = (n + kCluster - 1) / kCluster;
         for (uint32_t g = group0, c0 = 0; c0 < n_cl; ++g, c0 += kCluster) {
             const bool kg = keep.group(g);
             if (__ballot(kg) == 0ull) continue;
             const uint32_t c1 = (c0 + kCluster < n_cl) ? c0 + kCluster : n_cl;
-            for (uint32_t c = c0; c < c1; ++c) {
-                const bool kc = kg && keep.cluster(cluster0 + c);
-                if (__ballot(kc) == 0ull) continue;
-                const uint32_t i0 = c * kCluster;
-                const uint32_t i1 = (i0 + kCluster < n) ? i0 + kCluster : n;
-                for (uint32_t i = i0; i < i1; ++i) {
-                    const bool k = kc && keep.object(slot0 + i);
-                    if (__ballot(k) == 0ull) continue;
-                    const Rec rec = load_uniform(recs + i);
-                    if (k) body(rec, slot0 + i);
+            for (uint32_t cb = c0; cb < c1; cb += 4) {
+                bool kc4[4];
+                keep.cluster4(cluster0 + cb, kg, kc4);
+                for (uint32_t j = 0; j < 4; ++j) {
+                    const uint32_t c = cb + j;
+                    if (c >= c1 || __ballot(kc4[j]) == 0ull) continue;
+                    const uint32_t i0 = c * kCluster;
+                    const uint32_t i1 = (i0 + kCluster < n) ? i0 + kCluster : n;
+                    for (uint32_t ib = i0; ib < i1; ib += 4) {
+                        bool ko4[4];
+                        keep.object4(slot0 + ib, kc4[j], ko4);
+                        for (uint32_t e = 0; e < 4; ++e) {
+                            const uint32_t i = ib + e;
+                            if (i >= i1 || __ballot(ko4[e]) == 0ull) continue;
+                            const Rec rec = load_uniform(recs + i);
+                            if (ko4[e]) body(rec, slot0 + i);
+                        }
+                    }
                 }
             }
         }
@@ -391,8 +403,20 @@ struct SphereCull {
     R limit;
     const bool *stop;
     RT_DEV R t_max() const { return best ? Num<R>::min_(*best, limit) : limit; }
-    RT_DEV bool object(uint32_t slot) const { return !(stop && *stop) && may_hit<R, LINE>(load_uniform(bnd + slot), cr, t_max()); }
-    RT_DEV bool cluster(uint32_t c) const { return !(stop && *stop) && may_hit<R, LINE>(load_uniform(cl + c), cr, t_max()); }
+    struct Four {
+        BoundRec<R> b[4];
+    };
+    // four consecutive spheres in one fetch; entries past the end of the table are padding and
+    // their answers are ignored by the caller
+    RT_DEV void four(const BoundRec<R> *first, bool outer, bool *out) const
+    {
+        const Four f = load_uniform(reinterpret_cast<const Four *>(first));
+        const bool live = outer && !(stop && *stop);
+        const R tm = t_max();
+        for (int j = 0; j < 4; ++j) out[j] = live && may_hit<R, LINE>(f.b[j], cr, tm);
+    }
+    RT_DEV void object4(uint32_t slot, bool outer, bool *out) const { four(bnd + slot, outer, out); }
+    RT_DEV void cluster4(uint32_t c, bool outer, bool *out) const { four(cl + c, outer, out); }
     RT_DEV bool group(uint32_t g) const { return !(stop && *stop) && may_hit<R, LINE>(load_uniform(grp + g), cr, t_max()); }
 };
 

@@ -503,6 +503,12 @@ void fill_tables(const rtx_scene_desc *d, const std::vector<uint8_t> &container,
         t.slot_obj.push_back(i);
         t.bnd.push_back(store(bounds[i].c, bounds[i].r));
     }
+    // the walk fetches spheres four at a time: three entries of padding after the last
+    const double zero[3] = { 0.0, 0.0, 0.0 };
+    for (int k = 0; k < 3; ++k) {
+        t.bnd.push_back(store(zero, std::numeric_limits<double>::infinity()));
+        t.cl.push_back(store(zero, std::numeric_limits<double>::infinity()));
+    }
 }
 
 // One device allocation per scene and precision holding all tables back to back.
