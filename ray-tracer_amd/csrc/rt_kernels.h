@@ -100,21 +100,30 @@ RT_DEV void primary_ray(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> ro, V
         queue_push(out_q, sub, valid && nd.has_refract, nd.under_point, nd.refract_dir, nd.refract_factor, k, stats);
 }
 
-// Camera rays of rows [row0, row0 + n_rows): each wave takes one 64-pixel segment of a row,
-// one pixel per lane, so its framebuffer stores cover one contiguous run.  There is no loop:
-// the camera block is dead once the ray exists, which leaves the scalar register file to the
+// Camera rays of rows [row0, row0 + n_rows), one pixel per lane.  Each wave takes one 64-pixel
+// segment of a row, so its framebuffer stores cover one contiguous run; with bounding-sphere
+// tests it takes an 8x8 tile instead (camera_blocks() in rt_launch.h).  There is no loop: the
+// camera block is dead once the ray exists, which leaves the scalar register file to the
 // object tables.  The intersection walk reads the per-frame primary tables.
 #ifndef RTX_CAMERA_ATTR
 #define RTX_CAMERA_ATTR
 #endif
 template <typename R, uint32_t SF>
 __global__ void __launch_bounds__(kBlock) RTX_CAMERA_ATTR
-k_primary_camera(CameraDev<R> cam, SceneDev<R> S, PrimScene<R> P, uint32_t row0, uint32_t n_rows, uint32_t segs_per_row,
+k_primary_camera(CameraDev<R> cam, SceneDev<R> S, PrimScene<R> P, uint32_t row0, uint32_t n_rows, uint32_t pieces_per_row,
                  uint32_t remaining, R *__restrict__ fb, QueueDev<R> out_q, StatShard *__restrict__ stats)
 {
-    const uint32_t seg = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
-    const uint32_t row = seg / segs_per_row;
-    const uint32_t x = (seg - row * segs_per_row) * 64u + (threadIdx.x & 63u);
+    const uint32_t piece = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
+    const uint32_t piece_row = piece / pieces_per_row;
+    const uint32_t piece_col = piece - piece_row * pieces_per_row;
+    uint32_t row, x;
+    if constexpr ((SF & SF_CULL) != 0) {
+        row = piece_row * 8u + ((threadIdx.x >> 3) & 7u);
+        x = piece_col * 8u + (threadIdx.x & 7u);
+    } else {
+        row = piece_row;
+        x = piece_col * 64u + (threadIdx.x & 63u);
+    }
     const bool valid = row < n_rows && x < cam.hsize;
     V3<R> ro = { R(0), R(0), R(0) }, rd = ro;
     if (valid) ray_for_pixel(cam, x, row0 + row, ro, rd);
@@ -300,12 +309,11 @@ hipError_t Launch<R>::primary_camera(uint32_t sf, hipStream_t stream, const Came
                                      const PrimScene<R> &prim, uint32_t row0, uint32_t n_rows, uint32_t remaining, R *fb,
                                      const QueueDev<R> &out_q, StatShard *stats)
 {
-    const uint32_t segs_per_row = (cam.hsize + 63u) / 64u;
-    const uint64_t segs = (uint64_t)segs_per_row * n_rows;
-    const uint32_t grid = (uint32_t)((segs + kBlock / 64 - 1) / (kBlock / 64));
+    const uint32_t pieces_per_row = camera_pieces_per_row(sf, cam.hsize);
+    const uint32_t grid = (uint32_t)camera_blocks(sf, cam.hsize, n_rows);
 #define RTX_CALL(SFV)                                                                                               \
     hipLaunchKernelGGL((k_primary_camera<R, SFV | SF_PATTERN>), dim3(grid), dim3(kBlock), 0, stream, cam, scene, prim, \
-                       row0, n_rows, segs_per_row, remaining, fb, out_q, stats)
+                       row0, n_rows, pieces_per_row, remaining, fb, out_q, stats)
     RTX_SF_SWITCH(sf, RTX_CALL)
 #undef RTX_CALL
     return hipGetLastError();

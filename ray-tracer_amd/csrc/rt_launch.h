@@ -14,12 +14,19 @@ namespace rtx {
 // keeps loop-carried state out of the scalar registers the object records need.
 constexpr uint32_t kBlock = 256;
 
-// Workgroups of the camera kernel for n_rows rows of hsize pixels: a wave takes one 64-pixel
-// row segment, a workgroup four of them.
-inline uint64_t camera_blocks(uint32_t hsize, uint64_t n_rows)
+// Wave-sized pieces of the camera kernel's image for n_rows rows of hsize pixels.  Without
+// bounding-sphere tests a wave takes one 64-pixel row segment (its framebuffer stores are one
+// contiguous run).  With them it takes an 8x8 tile: the walk visits every sphere that any of
+// the wave's rays can hit, and a square bundle of rays touches fewer than a flat one.
+inline uint32_t camera_pieces_per_row(uint32_t sf, uint32_t hsize)
 {
-    const uint64_t segs = (uint64_t)((hsize + 63u) / 64u) * n_rows;
-    return (segs + kBlock / 64 - 1) / (kBlock / 64);
+    return (sf & SF_CULL) ? (hsize + 7u) / 8u : (hsize + 63u) / 64u;
+}
+inline uint64_t camera_blocks(uint32_t sf, uint32_t hsize, uint64_t n_rows)
+{
+    const uint64_t piece_rows = (sf & SF_CULL) ? (n_rows + 7u) / 8u : n_rows;
+    const uint64_t pieces = (uint64_t)camera_pieces_per_row(sf, hsize) * piece_rows;
+    return (pieces + kBlock / 64 - 1) / (kBlock / 64);
 }
 
 template <typename R>
