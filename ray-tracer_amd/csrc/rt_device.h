@@ -286,44 +286,48 @@ template <typename R> RT_DEV V3<R> twice(V3<R> o) { return { R(2) * o.x, R(2) * 
 // inflated on the host and the comparisons carry a rounding allowance, so a skipped object is
 // one for which the exact test would have found no intersection (in the range that counts):
 // results do not change.
+// The test's own arithmetic is not the reference's: it uses fused multiply-adds and a unit
+// direction, whatever the translation unit's contraction setting, to keep it short.
+RT_DEV double cull_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+RT_DEV float cull_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 template <typename R>
 struct CullRay {
-    V3<R> o, d;
-    R d2;    // d . d
-    R dlen;  // |d|
-    bool dead;  // the ray holds a NaN: it cannot hit anything
+    V3<R> o, u;  // origin, unit direction
+    R dlen;      // |d|: t of the ray times dlen is distance along u
+    bool dead;   // the ray holds a NaN: it cannot hit anything
 };
 template <typename R> RT_DEV CullRay<R> cull_ray(V3<R> o, V3<R> d)
 {
     CullRay<R> c;
     c.o = o;
-    c.d = d;
-    c.d2 = dot3(d, d);
-    c.dlen = Num<R>::sqrt_(c.d2);
+    const R d2 = dot3(d, d);
+    c.dlen = Num<R>::sqrt_(d2);
+    // a zero or infinite direction gives NaNs here, with which no comparison below skips
+    const R inv = R(1) / c.dlen;
+    c.u = { d.x * inv, d.y * inv, d.z * inv };
     // A NaN anywhere in the ray reaches every object-space coordinate (0 * NaN is NaN), so every
     // t of every shape is NaN and nothing is hit; without this the sphere tests, whose
     // comparisons are all false on NaN, would let such a ray through to all objects.
     const R oo = dot3(o, o);
-    c.dead = !(c.d2 == c.d2) || !(oo == oo);
+    c.dead = !(d2 == d2) || !(oo == oo);
     return c;
 }
 // LINE: intersections anywhere on the line count (the container bookkeeping of refraction reads
-// those behind the origin too).  Otherwise only 0 <= t <= t_max counts.
+// those behind the origin too).  Otherwise only 0 <= t <= t_max counts; reach = t_max * |d|.
 template <typename R, bool LINE>
-RT_DEV bool may_hit(const BoundRec<R> &b, const CullRay<R> &cr, R t_max)
+RT_DEV bool may_hit(const BoundRec<R> &b, const CullRay<R> &cr, R reach)
 {
     if (cr.dead) return false;
     const V3<R> m = { b.c[0] - cr.o.x, b.c[1] - cr.o.y, b.c[2] - cr.o.z };
-    const R tc = dot3(m, cr.d);
-    const R m2 = dot3(m, m);
+    const R tc = cull_fma(m.z, cr.u.z, cull_fma(m.y, cr.u.y, m.x * cr.u.x));
+    const R m2 = cull_fma(m.z, m.z, cull_fma(m.y, m.y, m.x * m.x));
     const R r2 = b.r * b.r;
-    const R md = m2 * cr.d2;
-    // d2 * (squared distance of the centre from the line) against d2 * r^2; r = inf never skips
-    if ((md - tc * tc) - r2 * cr.d2 > Num<R>::cull_slack * md) return false;
+    // squared distance of the centre from the line against r^2; r = inf never skips
+    if (cull_fma(-Num<R>::cull_slack, m2, cull_fma(-tc, tc, m2)) > r2) return false;
     if constexpr (!LINE) {
         if (tc < R(0) && m2 > r2) return false;  // the whole sphere lies behind the origin
-        // the ray enters the sphere no earlier than (tc - r |d|) / d2
-        if ((tc - b.r * cr.dlen) - Num<R>::cull_slack * Num<R>::abs_(tc) > t_max * cr.d2) return false;
+        // the ray is inside the sphere no earlier than tc - r along u
+        if (cull_fma(-Num<R>::cull_slack, Num<R>::abs_(tc), tc - b.r) > reach) return false;
     }
     return true;
 }
@@ -402,7 +406,7 @@ struct SphereCull {
     const R *best;
     R limit;
     const bool *stop;
-    RT_DEV R t_max() const { return best ? Num<R>::min_(*best, limit) : limit; }
+    RT_DEV R reach() const { return (best ? Num<R>::min_(*best, limit) : limit) * cr.dlen; }
     struct Four {
         BoundRec<R> b[4];
     };
@@ -412,12 +416,12 @@ struct SphereCull {
     {
         const Four f = load_uniform(reinterpret_cast<const Four *>(first));
         const bool live = outer && !(stop && *stop);
-        const R tm = t_max();
-        for (int j = 0; j < 4; ++j) out[j] = live && may_hit<R, LINE>(f.b[j], cr, tm);
+        const R rch = reach();
+        for (int j = 0; j < 4; ++j) out[j] = live && may_hit<R, LINE>(f.b[j], cr, rch);
     }
     RT_DEV void object4(uint32_t slot, bool outer, bool *out) const { four(bnd + slot, outer, out); }
     RT_DEV void cluster4(uint32_t c, bool outer, bool *out) const { four(cl + c, outer, out); }
-    RT_DEV bool group(uint32_t g) const { return !(stop && *stop) && may_hit<R, LINE>(load_uniform(grp + g), cr, t_max()); }
+    RT_DEV bool group(uint32_t g) const { return !(stop && *stop) && may_hit<R, LINE>(load_uniform(grp + g), cr, reach()); }
 };
 
 // Object::intersect for every object of the world (src/shapes/objects.rs:185-198 with

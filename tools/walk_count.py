@@ -1,0 +1,20 @@
+"""Counts the steps of the bounding-sphere walk (a library built with -DRTX_COUNT_WALK):
+RTX_LIB=... python3 tools/walk_count.py [hsize] [vsize]"""
+import ctypes, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from __graft_entry__ import load_package
+rta = load_package()
+from ray_tracer_amd import scenes
+W = int(sys.argv[1]) if len(sys.argv) > 1 else 960
+H = int(sys.argv[2]) if len(sys.argv) > 2 else 540
+w, cam = scenes.SCENES["random"](rta.api, hsize=W, vsize=H)
+lib = ctypes.CDLL(os.environ["RTX_LIB"])
+out = (ctypes.c_ulonglong * 8)()
+for depth in (0, 5):
+    lib.rtx_debug_walk(out, 1)
+    a = rta.render_rows(cam, w, depth=depth, precision=rta.F64)
+    assert lib.rtx_debug_walk(out, 1) == 0
+    waves = W * H / 64
+    print("depth %d  per primary wave: group fetches %.1f  cluster fetches %.1f  object fetches %.1f  leaves %.1f   checksum %.6f"
+          % (depth, out[0] / waves, out[1] / waves, out[2] / waves, out[3] / waves, float(a.sum())))
