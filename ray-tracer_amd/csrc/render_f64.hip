@@ -51,6 +51,52 @@ hipError_t launch_probe(uint32_t sf, uint32_t grid, hipStream_t stream, const Sc
     return hipGetLastError();
 }
 
+// Self-check of div3 against the plain divisions on n pseudo-random operand sets: exponents over
+// the whole f64 range (so both branches run), zeros, infinities, NaNs and denormals among them.
+// Counts the sets where any quotient differs in its bits (NaNs compare as equal to NaNs).
+__global__ void __launch_bounds__(kBlock)
+k_check_div3(uint64_t seed, uint32_t n, uint32_t narrow, unsigned long long *mismatches)
+{
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= n) return;
+    uint64_t st = seed + (uint64_t)k * 0x9e3779b97f4a7c15ull;
+    auto next = [&]() {
+        st += 0x9e3779b97f4a7c15ull;
+        uint64_t z = st;
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        return z ^ (z >> 31);
+    };
+    auto operand = [&]() {
+        uint64_t bits = next();
+        if (narrow) {  // exponent near 0: the shared-reciprocal branch
+            const uint64_t e = 1023u - 40u + (next() % 80u);
+            bits = (bits & 0x800fffffffffffffull) | (e << 52);
+        } else if ((next() & 15u) == 0u) {
+            const uint64_t special[6] = { 0ull, 0x8000000000000000ull, 0x7ff0000000000000ull, 0xfff0000000000000ull,
+                                          0x7ff8000000000000ull, 0x0000000000000001ull };
+            bits = special[next() % 6u];
+        }
+        return __builtin_bit_cast(double, bits);
+    };
+    const V3<double> a = { operand(), operand(), operand() };
+    const double b = operand();
+    const V3<double> q = div3(a, b);
+    const double want[3] = { a.x / b, a.y / b, a.z / b }, got[3] = { q.x, q.y, q.z };
+    bool bad = false;
+    for (int i = 0; i < 3; ++i) {
+        const bool both_nan = want[i] != want[i] && got[i] != got[i];
+        bad = bad || (!both_nan && __builtin_bit_cast(uint64_t, want[i]) != __builtin_bit_cast(uint64_t, got[i]));
+    }
+    if (bad) atomicAdd(mismatches, 1ull);
+}
+
+hipError_t launch_check_div3(hipStream_t stream, uint64_t seed, uint32_t n, uint32_t narrow, unsigned long long *mismatches)
+{
+    hipLaunchKernelGGL(k_check_div3, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, seed, n, narrow, mismatches);
+    return hipGetLastError();
+}
+
 template struct Launch<double>;
 
 }  // namespace rtx

@@ -62,6 +62,49 @@ template <> struct Num<float> {
 
 template <typename R> struct V3 { R x, y, z; };
 
+// ---- several quotients by one divisor ----------------------------------------------------
+// The compiler expands a / b in f64 into: v_div_scale of both operands (moves them away from the
+// exponent extremes), r0 = rcp(b), four FMAs that refine r0 to r, then m = a * r, the residual
+// e = fma(-b, m, a), the correction fma(e, r, m) (v_div_fmas) and v_div_fixup for NaN, infinity,
+// zero and denormal operands.  When every operand is an ordinary number with an exponent in
+// [-300, 300] the scaling is the identity and the fix-up passes the quotient through, so the
+// steps up to r depend on b alone.  Computing them once and the last three per numerator gives
+// the very bits of the separate divisions (correctly rounded quotients, as the reference's
+// divisions are) for 5 + 3k instructions instead of 11k.  Operands outside that range take the
+// plain divisions.
+RT_DEV uint32_t exponent_bits(double v) { return (uint32_t)(__builtin_bit_cast(uint64_t, v) >> 32) & 0x7fffffffu; }
+constexpr uint32_t kDivLo = (1023u - 300u) << 20, kDivHi = (1023u + 300u) << 20;
+RT_DEV bool ordinary(uint32_t e) { return e - kDivLo < kDivHi - kDivLo; }
+RT_DEV double refined_rcp(double b)
+{
+    const double r0 = __builtin_amdgcn_rcp(b);
+    const double e0 = __builtin_fma(-b, r0, 1.0);
+    const double r1 = __builtin_fma(r0, e0, r0);
+    const double e1 = __builtin_fma(-b, r1, 1.0);
+    return __builtin_fma(r1, e1, r1);
+}
+RT_DEV double quotient_with(double a, double b, double r)
+{
+    const double m = a * r;
+    return __builtin_fma(__builtin_fma(-b, m, a), r, m);
+}
+RT_DEV V3<double> div3(V3<double> a, double b)
+{
+    const uint32_t ex = exponent_bits(a.x), ey = exponent_bits(a.y), ez = exponent_bits(a.z);
+    const uint32_t lo = ex < ey ? (ex < ez ? ex : ez) : (ey < ez ? ey : ez);
+    const uint32_t hi = ex > ey ? (ex > ez ? ex : ez) : (ey > ez ? ey : ez);
+    if (lo >= kDivLo && hi < kDivHi && ordinary(exponent_bits(b))) {
+        const double r = refined_rcp(b);
+        return { quotient_with(a.x, b, r), quotient_with(a.y, b, r), quotient_with(a.z, b, r) };
+    }
+    return { a.x / b, a.y / b, a.z / b };
+}
+RT_DEV V3<float> div3(V3<float> a, float b)
+{
+    const float r = __builtin_amdgcn_rcpf(b);
+    return { a.x * r, a.y * r, a.z * r };
+}
+
 // src/matrices/tuples.rs:145-154
 template <typename R> RT_DEV R dot3(V3<R> a, V3<R> b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 // src/matrices/tuples.rs:58-73: magnitude, then three divisions
@@ -70,7 +113,7 @@ template <typename R> RT_DEV V3<R> normalize3(V3<R> a)
     const R m2 = (a.x * a.x + a.y * a.y) + a.z * a.z;
     if constexpr (Num<R>::exact) {
         const R mag = Num<R>::sqrt_(m2);
-        return { Num<R>::div(a.x, mag), Num<R>::div(a.y, mag), Num<R>::div(a.z, mag) };
+        return div3(a, mag);
     } else {
         const R r = __builtin_amdgcn_rsqf(m2);
         return { a.x * r, a.y * r, a.z * r };
@@ -874,7 +917,7 @@ RT_DEV Node<R> trace_node(const SceneDev<R> &S, const PrimScene<R> *P, V3<R> ro,
     // both normalise light.position - over_point; the vector is formed once here.
     V3<R> lvec = { S.light_pos[0] - over.x, S.light_pos[1] - over.y, S.light_pos[2] - over.z };
     R ldist = Num<R>::sqrt_((lvec.x * lvec.x + lvec.y * lvec.y) + lvec.z * lvec.z);
-    V3<R> lightv = { Num<R>::div(lvec.x, ldist), Num<R>::div(lvec.y, ldist), Num<R>::div(lvec.z, ldist) };
+    V3<R> lightv = div3(lvec, ldist);
     bool shadowed = is_shadowed<R, SF>(S, over, lightv, ldist);
     nd.shadowed = shadowed;
 

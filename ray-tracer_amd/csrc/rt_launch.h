@@ -62,6 +62,9 @@ struct Launch {
 hipError_t launch_probe(uint32_t sf, uint32_t grid, hipStream_t stream, const SceneDev<double> &scene,
                         const double *rays, uint32_t n, rtx_probe *out);
 
+// f64 only: counts operand sets on which the shared-reciprocal quotients differ from plain divisions.
+hipError_t launch_check_div3(hipStream_t stream, uint64_t seed, uint32_t n, uint32_t narrow, unsigned long long *mismatches);
+
 extern template struct Launch<double>;
 extern template struct Launch<float>;
 

@@ -1203,6 +1203,29 @@ int rtx_probe_rays(rtx_context *ctx, const rtx_scene *scene, const double *rays,
     return RTX_OK;
 }
 
+int rtx_selfcheck_division(rtx_context *ctx, uint64_t seed, uint32_t n, int narrow, uint64_t *mismatches)
+{
+    if (!ctx || !mismatches) return fail(RTX_ERR_INVALID, "ctx or mismatches is NULL");
+    if (n == 0 || n > 0x7fffff00u) return fail(RTX_ERR_INVALID, "n must be between 1 and 2^31 - 256");
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return fail(RTX_ERR_DEVICE, "hipSetDevice(%d) failed", ctx->device);
+    SlotLease lease(ctx);
+    int rc = slot_acquire(ctx, &lease.slot);
+    if (rc) return rc;
+    Slot *slot = lease.slot;
+    rc = grow(&slot->aux, &slot->aux_bytes, 256);
+    if (rc) return rc;
+    rc = slot_order_after_pending(slot, slot->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(slot->aux, 0, sizeof(unsigned long long), slot->stream));
+    HIP_TRY(launch_check_div3(slot->stream, seed, n, narrow ? 1u : 0u, (unsigned long long *)slot->aux));
+    unsigned long long count = 0;
+    HIP_TRY(hipMemcpyAsync(&count, slot->aux, sizeof count, hipMemcpyDeviceToHost, slot->stream));
+    HIP_TRY(hipStreamSynchronize(slot->stream));
+    *mismatches = count;
+    return RTX_OK;
+}
+
 int rtx_generate_rays(rtx_context *ctx, const rtx_camera_desc *camera, uint64_t first_pixel, size_t n, double *out)
 {
     if (!ctx) return fail(RTX_ERR_INVALID, "ctx is NULL");

@@ -496,3 +496,17 @@ def test_full_size_frame_properties(orc, rta):
     # set of lit pixels per row is symmetric to within one pixel
     mask = img.sum(axis=2) > 0
     assert np.abs(mask.sum(axis=1) - mask[:, ::-1].sum(axis=1)).max() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("narrow", [1, 0])
+def test_shared_reciprocal_quotients_are_the_bits_of_plain_divisions(rta, narrow):
+    """Tuple::normalize divides three components by one magnitude (src/matrices/tuples.rs:58-73);
+    the kernels share the reciprocal refinement between the three.  4M operand sets per case:
+    exponents near 0 (the shortcut) and the whole f64 range with specials (the fallback)."""
+    import ctypes as C
+    ctx = rta.Context(0)
+    bad = C.c_uint64(123)
+    for seed in (1, 0xDEADBEEF):
+        rta._check(rta.rtx_selfcheck_division(ctx.h, seed, 1 << 22, narrow, C.byref(bad)))
+        assert bad.value == 0
