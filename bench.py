@@ -280,6 +280,9 @@ def main():
                 "kernel_ms": k_ms,
                 "algorithmic_flops_per_launch": flops_tile,
                 "bounding_sphere_tests": scene.features()["bounding_sphere_tests"],
+                # with bounding-sphere tests most of the algorithm's ray/object tests are never executed:
+                # "achieved" then counts work that was skipped and "frac" says nothing about the ALUs
+                "frac_is_meaningful": not scene.features()["bounding_sphere_tests"],
                 "hbm_write_GBps": n_pix_tile * 3 * tile.element_size() / (k_ms * 1e-3) / 1e9,
             },
             "frame": {
