@@ -177,9 +177,22 @@ k_bounce(SceneDev<R> S, QueueDev<R> in_q, QueueDev<R> out_q, uint32_t remaining,
     const uint32_t sub_in = blockIdx.y;
     uint32_t n = in_q.count[(size_t)sub_in * kCountStride];
     if (n > in_q.cap_sub) n = in_q.cap_sub;
-    if (blockIdx.x * kBlock >= n) return;
-    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
-    const bool valid = k < n;
+    // With bounding-sphere tests a wave walks the union of the spheres its rays can hit, one
+    // dependent fetch after another, and deep levels hold few, incoherent rays: their waves are
+    // long chains on a mostly idle chip.  While a level is short enough that the whole chip has
+    // lanes to spare, give every ray `spread` lanes' worth of room (one ray per `spread` lanes):
+    // more, shorter walks side by side.  The grid covers the worst-case length, so the room is
+    // there; the decision is uniform over the launch's y slice.
+    uint32_t spread = 1u;
+    if constexpr ((SF & SF_CULL) != 0) {
+        const uint32_t budget = kSpreadLanes / gridDim.y;  // lanes per sub-queue when the chip is lightly loaded
+        while (spread < 64u && (uint64_t)n * (spread * 2u) <= budget && (uint64_t)n * (spread * 2u) <= (uint64_t)gridDim.x * kBlock)
+            spread *= 2u;
+    }
+    if ((uint64_t)blockIdx.x * kBlock >= (uint64_t)n * spread) return;
+    const uint32_t lane_slot = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t k = lane_slot / spread;
+    const bool valid = k < n && (lane_slot & (spread - 1u)) == 0u;
     Node<R> nd;
     nd.hit = false;
     nd.has_reflect = nd.has_refract = false;

@@ -188,6 +188,8 @@ struct QueueDev {
 };
 
 // Per-level counters, one block of shards per render call (summed on the host).
+// lanes of a lightly loaded chip: 1024 SIMDs x 4 waves x 64 (k_bounce spreads short levels over them)
+constexpr uint32_t kSpreadLanes = 1024u * 4u * 64u;
 constexpr int kStatShards = 256;
 struct StatShard {
     unsigned long long hits[8];  // shaded hits (= is_shadowed calls) per recursion level
