@@ -279,12 +279,45 @@ def test_row_tiles_and_chunks_agree(orc, rta):
     ctx.close()
 
 
+def test_tiled_camera_rays_in_chunks_lower_than_a_tile(orc, rta):
+    """With bounding-sphere tests a wave takes an 8x8 tile of the image; a workspace so small
+    that chunks are lower than a tile (down to single rows) must still give the frame of one
+    call, and so must row ranges that start inside a tile."""
+    from ray_tracer_amd import scenes
+    w, cam = scenes.random_scene(rta.api, n_objects=150, hsize=2001, vsize=21, seed=11)  # reflective only: one child per hit
+    flat = rta.flatten(w)
+    cd = rta.camera_desc(cam)
+    frames = []
+    for limit in (None, 2 << 20, 1 << 20):
+        ctx = rta.Context()
+        ctx.set_cull_threshold(0)
+        if limit:
+            ctx.set_workspace_limit(limit)
+        scene = rta.Scene(ctx, flat)
+        assert scene.features()["bounding_sphere_tests"]
+        out = np.empty((21, 2001, 3))
+        st = rta.Stats()
+        rta._check(rta.rtx_render(ctx.h, scene.h, cd, 5, rta.F64, 0, 21, out.ctypes.data, out.nbytes, None, None, st))
+        frames.append((out, st.n_chunks, st.color_rays, st.shadow_rays))
+        if limit is None:
+            part = np.empty((9, 2001, 3))
+            rta._check(rta.rtx_render(ctx.h, scene.h, cd, 5, rta.F64, 5, 14, part.ctypes.data, part.nbytes, None, None, None))
+            assert np.abs(part - out[5:14]).max() <= 1e-12
+        scene.close()
+        ctx.close()
+    assert frames[0][1] == 1 and frames[1][1] > 1 and frames[2][1] >= 5  # 1 MiB: chunks of about 4 rows, lower than a tile
+    for out, _, cr, sr in frames[1:]:
+        assert (cr, sr) == frames[0][2:]
+        assert np.abs(out - frames[0][0]).max() <= 1e-12
+
+
 def test_bounding_sphere_tests_change_nothing(orc, rta):
     """Ray counters and colours do not depend on whether objects are skipped by their bounding
     spheres (threshold 0 = always test, 2^32-1 = never).  Colours are compared to 1e-12: the
     terms of a pixel's sum are added atomically, in an order that varies from run to run."""
     from ray_tracer_amd import scenes
-    cases = [(scenes.glass_scene, dict(hsize=96, vsize=54)), (scenes.random_scene, dict(n_objects=200, hsize=96, vsize=54))]
+    cases = [(scenes.glass_scene, dict(hsize=96, vsize=54)), (scenes.random_scene, dict(n_objects=200, hsize=96, vsize=54)),
+             (scenes.random_scene, dict(n_objects=90, hsize=101, vsize=53, seed=7))]  # a ragged last tile column and row
     cases += [(shapes_scene, dict(kind=k)) for k in range(4)]
     cases += [(unit_shapes_scene, dict(shape=s)) for s in range(7)]
     frames = {}
