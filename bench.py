@@ -153,8 +153,14 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render loop has no CPU path")
     torch.cuda.set_device(local_rank)
-    if world_size > 1:
+    # RTX_BENCH_DIST=1 takes the multi-rank code path (process group, gather, reductions) with a
+    # single rank too: a rehearsal of that path on a one-GPU box, not a measurement
+    distributed = world_size > 1 or os.environ.get("RTX_BENCH_DIST") == "1"
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     n_gpus = world_size
     rta = entry.load_package()
@@ -178,15 +184,17 @@ def main():
     stream = tstream.cuda_stream
     assert stream != 0
 
+    frame = torch.empty((args.height, args.width, 3), dtype=tdtype, device="cuda") if distributed and rank == 0 else None
+
     def step():
         rta.render_device(ctx, scene, cd, args.depth, prec, r0, r1, tile.data_ptr(), tile.numel() * tile.element_size(), stream)
-        if world_size > 1:
-            return sharding.gather_frame(tile, tiles, args.width, dst=0)
+        if distributed:
+            return sharding.gather_frame(tile, tiles, args.width, dst=0, out=frame)
         return tile
 
     def fence():
         torch.cuda.synchronize()
-        if world_size > 1:
+        if distributed:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -227,7 +235,7 @@ def main():
         host_rgba8_ms = min(host_rgba8_ms, (time.perf_counter() - t_h) * 1e3)
 
     vals = torch.tensor([wall, float(st["color_rays"]), float(st["shadow_rays"])], dtype=torch.float64, device="cuda")
-    if world_size > 1:
+    if distributed:
         mx = vals.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = vals.clone()
@@ -299,7 +307,7 @@ def main():
             out["extra"] = extra_scenes(rta, ctx, args)
         print(json.dumps(out))
     scene.close()
-    if world_size > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

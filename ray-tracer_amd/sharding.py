@@ -25,10 +25,11 @@ def row_tiles(vsize, world_size, band=BAND_SIZE):
     return tiles
 
 
-def gather_frame(local, tiles, hsize, dst=0, group=None):
+def gather_frame(local, tiles, hsize, dst=0, group=None, out=None):
     """Send every rank's tile (rows, hsize, C tensor) to `dst`; returns the assembled
     (vsize, hsize, C) frame there and None elsewhere.  Tiles are padded to the tallest tile so
-    that one fixed-size gather moves them."""
+    that one fixed-size gather moves them.  `out`: a (vsize, hsize, C) tensor to assemble into on
+    `dst` (a frame loop reuses one instead of allocating per frame)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     chans = local.shape[-1]
@@ -43,15 +44,16 @@ def gather_frame(local, tiles, hsize, dst=0, group=None):
     send = send.contiguous()
     if rank == dst:
         vsize = tiles[-1][1]
+        if out is not None and (tuple(out.shape) != (vsize, hsize, chans) or out.dtype != local.dtype or not out.is_contiguous()):
+            raise ValueError("out must be a contiguous (%d, %d, %d) tensor of %s" % (vsize, hsize, chans, local.dtype))
         if all(r1 - r0 == max_rows for r0, r1 in tiles):
             # equal tiles: receive straight into the frame, no staging copy
-            frame = torch.empty((vsize, hsize, chans), dtype=local.dtype, device=local.device)
+            frame = out if out is not None else torch.empty((vsize, hsize, chans), dtype=local.dtype, device=local.device)
             dist.gather(send, gather_list=[frame[r0:r1] for r0, r1 in tiles], dst=dst, group=group)
             return frame
         parts = [torch.empty_like(send) for _ in range(world)]
         dist.gather(send, gather_list=parts, dst=dst, group=group)
-        vsize = tiles[-1][1]
-        frame = torch.empty((vsize, hsize, chans), dtype=local.dtype, device=local.device)
+        frame = out if out is not None else torch.empty((vsize, hsize, chans), dtype=local.dtype, device=local.device)
         for (r0, r1), part in zip(tiles, parts):
             frame[r0:r1] = part[: r1 - r0]
         return frame

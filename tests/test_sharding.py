@@ -55,7 +55,11 @@ def _rank_main(rank, world, port, hsize, vsize, out_path):
         a, b = tiles[rank]
         local = torch.from_numpy(orc.render_rows(cam, w, row_begin=a, row_end=b)) if b > a else torch.empty((0, hsize, 3), dtype=torch.float64)
         frame = sharding.gather_frame(local, tiles, hsize, dst=0)
+        # a second frame into a caller-owned buffer, as a frame loop does
+        mine = torch.full((vsize, hsize, 3), -1.0, dtype=torch.float64) if rank == 0 else None
+        again = sharding.gather_frame(local, tiles, hsize, dst=0, out=mine)
         if rank == 0:
+            assert again is mine and torch.equal(mine, frame)
             whole = orc.render_rows(cam, w)
             np.save(out_path, np.array([float(np.abs(frame.numpy() - whole).max()), float(frame.shape[0])]))
         else:
