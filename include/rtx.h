@@ -155,14 +155,21 @@ int rtx_render(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_desc *
                rtx_progress_fn progress, void *user, rtx_stats *stats);
 
 /*
- * rtx_render followed by the reference's 8-bit conversion, done on the device so that only
- * bytes cross PCIe: channels = 3 gives Canvas::canvas_to_png's RGB (src/scenes/canvas.rs:80-92),
- * channels = 4 gives Canvas::canvas_to_buffer's RGBA with alpha 255 (canvas.rs:94-104, what the
- * GUI displays); every channel is `(c * 255.999) as u8` (saturating, NaN -> 0).  out holds
- * (row_end-row_begin)*hsize*channels bytes, row-major.
+ * rtx_render followed by one of the reference's 8-bit conversions, done on the device so that
+ * only bytes cross PCIe.  format:
+ *   RTX_PIXELS_RGB8   Canvas::canvas_to_png's RGB (src/scenes/canvas.rs:80-92),
+ *   RTX_PIXELS_RGBA8  Canvas::canvas_to_buffer's RGBA with alpha 255 (canvas.rs:94-104, what the
+ *                     GUI displays); both take every channel as `(c * 255.999) as u8`,
+ *   RTX_PIXELS_PPM8   the numbers Canvas::canvas_to_ppm prints (canvas.rs:52-71):
+ *                     `(c * 255.0) as isize` clamped to 0..255, three bytes per pixel.
+ * All casts truncate toward zero, saturate and send NaN to 0, as Rust's `as` does.  out holds
+ * (row_end-row_begin)*hsize*(format & 0xff) bytes, row-major.
  */
+#define RTX_PIXELS_RGB8 3u
+#define RTX_PIXELS_RGBA8 4u
+#define RTX_PIXELS_PPM8 0x103u
 int rtx_render_8bit(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_desc *camera, uint32_t max_depth,
-                    int precision, uint32_t row_begin, uint32_t row_end, uint32_t channels, uint8_t *out, size_t out_bytes,
+                    int precision, uint32_t row_begin, uint32_t row_end, uint32_t format, uint8_t *out, size_t out_bytes,
                     rtx_progress_fn progress, void *user, rtx_stats *stats);
 
 /*

@@ -119,6 +119,8 @@ rtx_scene_destroy = _bind("rtx_scene_destroy", None, [_vp])
 rtx_scene_features = _bind("rtx_scene_features", C.c_int, [_vp, C.POINTER(C.c_uint32)])
 rtx_render = _bind("rtx_render", C.c_int, [_vp, _vp, C.POINTER(CameraDesc), C.c_uint32, C.c_int, C.c_uint32, C.c_uint32,
                                            _vp, C.c_size_t, _vp, _vp, C.POINTER(Stats)])
+# pixel formats of rtx_render_8bit (include/rtx.h)
+PIXELS_RGB8, PIXELS_RGBA8, PIXELS_PPM8 = 3, 4, 0x103
 rtx_render_8bit = _bind("rtx_render_8bit", C.c_int, [_vp, _vp, C.POINTER(CameraDesc), C.c_uint32, C.c_int, C.c_uint32, C.c_uint32,
                                                      C.c_uint32, _vp, C.c_size_t, _vp, _vp, C.POINTER(Stats)])
 rtx_render_device = _bind("rtx_render_device", C.c_int, [_vp, _vp, C.POINTER(CameraDesc), C.c_uint32, C.c_int, C.c_uint32,

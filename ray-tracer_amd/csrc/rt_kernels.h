@@ -258,23 +258,26 @@ __global__ void __launch_bounds__(kBlock) k_quantize(const R *__restrict__ rgb, 
 }
 
 // Canvas::canvas_to_png / canvas_to_buffer (src/scenes/canvas.rs:80-104): one pixel per thread,
-// three channels `(c * 255.999) as u8`, and with channels == 4 an alpha byte of 255.
-template <typename R> RT_DEV uint32_t to_u8(R c)
+// three channels `(c * 255.999) as u8`, and with four bytes per pixel an alpha byte of 255.
+// Canvas::canvas_to_ppm (canvas.rs:52-71) scales by 255.0 instead, casts to isize and clamps to
+// 0..255.  Both casts truncate toward zero, saturate and send NaN to 0, so one routine serves.
+template <typename R> RT_DEV uint32_t to_u8(R c, R scale)
 {
-    const R v = c * R(255.999);
+    const R v = c * scale;
     if (!(v == v) || v <= R(0)) return 0u;
     if (v >= R(255)) return 255u;
     return (uint32_t)(int)v;
 }
 template <typename R>
 __global__ void __launch_bounds__(kBlock)
-k_pack8(const R *__restrict__ rgb, uint32_t n_pix, uint32_t channels, uint8_t *__restrict__ out)
+k_pack8(const R *__restrict__ rgb, uint32_t n_pix, uint32_t format, uint8_t *__restrict__ out)
 {
     const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= n_pix) return;
+    const R scale = (format >> 8) ? R(255.0) : R(255.999);
     const R *c = rgb + (size_t)p * 3;
-    const uint32_t r = to_u8(c[0]), g = to_u8(c[1]), b = to_u8(c[2]);
-    if (channels == 4) {
+    const uint32_t r = to_u8(c[0], scale), g = to_u8(c[1], scale), b = to_u8(c[2], scale);
+    if ((format & 0xffu) == 4u) {
         reinterpret_cast<uint32_t *>(out)[p] = r | (g << 8) | (b << 16) | (255u << 24);
     } else {
         uint8_t *o = out + (size_t)p * 3;
@@ -390,10 +393,10 @@ hipError_t Launch<R>::quantize(uint32_t grid, hipStream_t stream, const R *rgb, 
 }
 
 template <typename R>
-hipError_t Launch<R>::pack8(hipStream_t stream, const R *rgb, uint32_t n_pix, uint32_t channels, uint8_t *out)
+hipError_t Launch<R>::pack8(hipStream_t stream, const R *rgb, uint32_t n_pix, uint32_t format, uint8_t *out)
 {
     if (n_pix == 0) return hipSuccess;
-    hipLaunchKernelGGL((k_pack8<R>), dim3((n_pix + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, rgb, n_pix, channels, out);
+    hipLaunchKernelGGL((k_pack8<R>), dim3((n_pix + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, rgb, n_pix, format, out);
     return hipGetLastError();
 }
 

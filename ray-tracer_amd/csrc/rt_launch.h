@@ -52,8 +52,9 @@ struct Launch {
     // Primary rays only (no tracing): out[6*k..] = origin, direction.
     static hipError_t raygen(uint32_t grid, hipStream_t stream, const CameraDev<R> &cam, uint32_t pix_begin,
                              uint32_t n_pix, double *out);
-    // 8-bit pixels: 3 or 4 bytes each (alpha 255) from 3 values each
-    static hipError_t pack8(hipStream_t stream, const R *rgb, uint32_t n_pix, uint32_t channels, uint8_t *out);
+    // 8-bit pixels from 3 values each; format: an RTX_PIXELS_* value (bytes per pixel in the low byte,
+    // conversion rule above it)
+    static hipError_t pack8(hipStream_t stream, const R *rgb, uint32_t n_pix, uint32_t format, uint8_t *out);
     // (c * 255.999) as u8
     static hipError_t quantize(uint32_t grid, hipStream_t stream, const R *rgb, size_t n, uint8_t *out);
 };

@@ -829,7 +829,7 @@ int render_impl(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_desc 
                 uint32_t row_begin, uint32_t row_end, void *host_out, void *dev_out, hipStream_t user_stream,
                 rtx_progress_fn progress, void *user, rtx_stats *stats, uint32_t channels8 = 0)
 {
-    // channels8 != 0: host_out receives 8-bit pixels of that many channels instead of R values
+    // channels8 != 0: an RTX_PIXELS_* format; host_out receives 8-bit pixels instead of R values
     const auto t0 = std::chrono::steady_clock::now();
     DeviceGuard guard(ctx->device);
     if (!guard.ok) return fail(RTX_ERR_DEVICE, "hipSetDevice(%d) failed", ctx->device);
@@ -862,10 +862,11 @@ int render_impl(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_desc 
         return RTX_OK;
     }
     if (host_out && channels8) {
-        rc = grow(&slot->aux, &slot->aux_bytes, (size_t)(n_pix * channels8));
+        const size_t pixel_bytes = channels8 & 0xffu;
+        rc = grow(&slot->aux, &slot->aux_bytes, (size_t)(n_pix * pixel_bytes));
         if (rc) return rc;
         HIP_TRY(Launch<R>::pack8(stream, d_fb, (uint32_t)n_pix, channels8, (uint8_t *)slot->aux));
-        rc = copy_to_host(slot, stream, host_out, slot->aux, (size_t)(n_pix * channels8));
+        rc = copy_to_host(slot, stream, host_out, slot->aux, (size_t)(n_pix * pixel_bytes));
         if (rc) return rc;
     } else if (host_out) {
         rc = copy_to_host(slot, stream, host_out, d_fb, (size_t)(n_pix * 3 * sizeof(R)));
@@ -1129,15 +1130,16 @@ int rtx_render(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_desc *
 }
 
 int rtx_render_8bit(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_desc *camera, uint32_t max_depth, int precision,
-                    uint32_t row_begin, uint32_t row_end, uint32_t channels, uint8_t *out, size_t out_bytes,
+                    uint32_t row_begin, uint32_t row_end, uint32_t format, uint8_t *out, size_t out_bytes,
                     rtx_progress_fn progress, void *user, rtx_stats *stats)
 {
     if (!ctx || !scene || scene->ctx != ctx) return fail(RTX_ERR_INVALID, "scene does not belong to this context");
     int rc = check_camera(camera, row_begin, row_end);
     if (rc) return rc;
     if (precision != RTX_F64 && precision != RTX_F32) return fail(RTX_ERR_INVALID, "unknown precision %d", precision);
-    if (channels != 3 && channels != 4) return fail(RTX_ERR_INVALID, "channels must be 3 (RGB) or 4 (RGBA), not %u", channels);
-    const size_t need = (size_t)(row_end - row_begin) * camera->hsize * channels;
+    if (format != RTX_PIXELS_RGB8 && format != RTX_PIXELS_RGBA8 && format != RTX_PIXELS_PPM8)
+        return fail(RTX_ERR_INVALID, "format must be RTX_PIXELS_RGB8 (3), RTX_PIXELS_RGBA8 (4) or RTX_PIXELS_PPM8 (0x103), not %u", format);
+    const size_t need = (size_t)(row_end - row_begin) * camera->hsize * (format & 0xffu);
     if (need && (!out || out_bytes < need)) return fail(RTX_ERR_INVALID, "output buffer holds %zu bytes, %zu needed", out_bytes, need);
     if (need == 0) {
         if (stats) std::memset(stats, 0, sizeof *stats);
@@ -1145,9 +1147,9 @@ int rtx_render_8bit(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_d
     }
     if (precision == RTX_F64)
         return render_impl<double>(ctx, scene, camera, max_depth, row_begin, row_end, out, nullptr, nullptr, progress, user, stats,
-                                   channels);
+                                   format);
     return render_impl<float>(ctx, scene, camera, max_depth, row_begin, row_end, out, nullptr, nullptr, progress, user, stats,
-                              channels);
+                              format);
 }
 
 int rtx_render_device(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_desc *camera, uint32_t max_depth,

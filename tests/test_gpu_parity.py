@@ -366,6 +366,11 @@ def test_8bit_output_matches_the_reference_conversion(orc, rta):
             assert np.array_equal(got[:, :, :3], want)
             if channels == 4:
                 assert (got[:, :, 3] == 255).all()
+        # the PPM writer's rule, `(c * 255.0) as isize` clamped to 0..255 (canvas.rs:52-71)
+        ppm = np.zeros((H, W, 3), dtype=np.uint8)
+        rta._check(rta.rtx_render_8bit(ctx.h, scene.h, cd, 5, rta.F64, 0, H, rta.PIXELS_PPM8, ppm.ctypes.data, ppm.nbytes, None, None, None))
+        assert np.array_equal(ppm, orc.quantize_ppm(full).astype(np.uint8))
+        assert (ppm != want).any()  # the two rules differ somewhere on a real frame
         part = np.zeros((H - 13, W, 3), dtype=np.uint8)
         rta._check(rta.rtx_render_8bit(ctx.h, scene.h, cd, 5, rta.F64, 10, H - 3, 3, part.ctypes.data, part.nbytes, None, None, None))
         assert np.array_equal(part, want[10:H - 3])
