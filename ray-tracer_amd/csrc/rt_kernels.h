@@ -70,7 +70,7 @@ RT_DEV void count_hits(StatShard *__restrict__ stats, uint32_t group, uint32_t l
     if (mask == 0ull) return;
     const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
     if (lane_id() == leader) {
-        const uint32_t wave = group * (kBlock / 64) + (threadIdx.x >> 6);
+        const uint32_t wave = group * (blockDim.x >> 6) + (threadIdx.x >> 6);
         atomicAdd(&stats[wave % kStatShards].hits[level], (unsigned long long)__popcll(mask));
     }
 }
@@ -109,11 +109,11 @@ RT_DEV void primary_ray(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> ro, V
 #define RTX_CAMERA_ATTR
 #endif
 template <typename R, uint32_t SF>
-__global__ void __launch_bounds__(kBlock) RTX_CAMERA_ATTR
+__global__ void __launch_bounds__(kCamBlock) RTX_CAMERA_ATTR
 k_primary_camera(CameraDev<R> cam, SceneDev<R> S, PrimScene<R> P, uint32_t row0, uint32_t n_rows, uint32_t pieces_per_row,
                  uint32_t remaining, R *__restrict__ fb, QueueDev<R> out_q, StatShard *__restrict__ stats)
 {
-    const uint32_t piece = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
+    const uint32_t piece = __builtin_amdgcn_readfirstlane(blockIdx.x * (kCamBlock / 64) + (threadIdx.x >> 6));
     const uint32_t piece_row = piece / pieces_per_row;
     const uint32_t piece_col = piece - piece_row * pieces_per_row;
     uint32_t row, x;
@@ -132,12 +132,12 @@ k_primary_camera(CameraDev<R> cam, SceneDev<R> S, PrimScene<R> P, uint32_t row0,
 
 // Rays from a caller-supplied array (World::color_at batches), one per thread.
 template <typename R, uint32_t SF>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kRayBlock<R>)
 k_primary_rays(SceneDev<R> S, const double *__restrict__ rays, uint32_t n, uint32_t remaining, R *__restrict__ fb,
                QueueDev<R> out_q, StatShard *__restrict__ stats)
 {
     const PrimScene<R> none = {};
-    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t k = blockIdx.x * kRayBlock<R> + threadIdx.x;
     const bool valid = k < n;
     V3<R> ro = { R(0), R(0), R(0) }, rd = ro;
     if (valid) {
@@ -170,7 +170,7 @@ template <> RT_DEV void fb_add<float>(float *p, float v) { unsafeAtomicAdd(p, v)
 // once.  The children go to sub-queue (x + y) mod n_sub: every output sub-queue is fed by
 // exactly gridDim.x workgroups, which is the bound the host sizes cap_sub with.
 template <typename R, uint32_t SF>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kRayBlock<R>)
 k_bounce(SceneDev<R> S, QueueDev<R> in_q, QueueDev<R> out_q, uint32_t remaining, uint32_t level,
          R *__restrict__ fb, StatShard *__restrict__ stats)
 {
@@ -186,11 +186,11 @@ k_bounce(SceneDev<R> S, QueueDev<R> in_q, QueueDev<R> out_q, uint32_t remaining,
     uint32_t spread = 1u;
     if constexpr ((SF & SF_CULL) != 0) {
         const uint32_t budget = kSpreadLanes / gridDim.y;  // lanes per sub-queue when the chip is lightly loaded
-        while (spread < 64u && (uint64_t)n * (spread * 2u) <= budget && (uint64_t)n * (spread * 2u) <= (uint64_t)gridDim.x * kBlock)
+        while (spread < 64u && (uint64_t)n * (spread * 2u) <= budget && (uint64_t)n * (spread * 2u) <= (uint64_t)gridDim.x * kRayBlock<R>)
             spread *= 2u;
     }
-    if ((uint64_t)blockIdx.x * kBlock >= (uint64_t)n * spread) return;
-    const uint32_t lane_slot = blockIdx.x * kBlock + threadIdx.x;
+    if ((uint64_t)blockIdx.x * kRayBlock<R> >= (uint64_t)n * spread) return;
+    const uint32_t lane_slot = blockIdx.x * kRayBlock<R> + threadIdx.x;
     const uint32_t k = lane_slot / spread;
     const bool valid = k < n && (lane_slot & (spread - 1u)) == 0u;
     Node<R> nd;
@@ -328,7 +328,7 @@ hipError_t Launch<R>::primary_camera(uint32_t sf, hipStream_t stream, const Came
     const uint32_t pieces_per_row = camera_pieces_per_row(sf, cam.hsize);
     const uint32_t grid = (uint32_t)camera_blocks(sf, cam.hsize, n_rows);
 #define RTX_CALL(SFV)                                                                                               \
-    hipLaunchKernelGGL((k_primary_camera<R, SFV | SF_PATTERN>), dim3(grid), dim3(kBlock), 0, stream, cam, scene, prim, \
+    hipLaunchKernelGGL((k_primary_camera<R, SFV | SF_PATTERN>), dim3(grid), dim3(kCamBlock), 0, stream, cam, scene, prim, \
                        row0, n_rows, pieces_per_row, remaining, fb, out_q, stats)
     RTX_SF_SWITCH(sf, RTX_CALL)
 #undef RTX_CALL
@@ -339,9 +339,9 @@ template <typename R>
 hipError_t Launch<R>::primary_rays(uint32_t sf, hipStream_t stream, const SceneDev<R> &scene, const double *rays,
                                    uint32_t n, uint32_t remaining, R *fb, const QueueDev<R> &out_q, StatShard *stats)
 {
-    const uint32_t grid = (n + kBlock - 1) / kBlock;
+    const uint32_t grid = (n + kRayBlock<R> - 1) / kRayBlock<R>;
 #define RTX_CALL(SFV)                                                                                           \
-    hipLaunchKernelGGL((k_primary_rays<R, SFV | SF_PATTERN>), dim3(grid), dim3(kBlock), 0, stream, scene, rays, n, \
+    hipLaunchKernelGGL((k_primary_rays<R, SFV | SF_PATTERN>), dim3(grid), dim3(kRayBlock<R>), 0, stream, scene, rays, n, \
                        remaining, fb, out_q, stats)
     RTX_SF_SWITCH(sf, RTX_CALL)
 #undef RTX_CALL
@@ -367,10 +367,10 @@ hipError_t Launch<R>::bounce(uint32_t sf, hipStream_t stream, const SceneDev<R> 
                              const QueueDev<R> &out_q, uint32_t remaining, uint32_t level, R *fb, StatShard *stats)
 {
     if ((sf & (SF_REFLECTIVE | SF_TRANSPARENT)) == 0 || in_q.cap_sub == 0) return hipSuccess;  // nothing can be queued
-    const dim3 grid((in_q.cap_sub + kBlock - 1) / kBlock, in_q.sub_mask + 1);
+    const dim3 grid((in_q.cap_sub + kRayBlock<R> - 1) / kRayBlock<R>, in_q.sub_mask + 1);
 #define RTX_CALL(SFV)                                                                                   \
     if constexpr (((SFV) & (SF_REFLECTIVE | SF_TRANSPARENT)) != 0)                                      \
-        hipLaunchKernelGGL((k_bounce<R, SFV | SF_PATTERN>), grid, dim3(kBlock), 0, stream, scene, in_q, \
+        hipLaunchKernelGGL((k_bounce<R, SFV | SF_PATTERN>), grid, dim3(kRayBlock<R>), 0, stream, scene, in_q, \
                            out_q, remaining, level, fb, stats)
     RTX_SF_SWITCH(sf, RTX_CALL)
 #undef RTX_CALL

@@ -627,14 +627,14 @@ struct FramePlan {
 };
 
 // Queue sizes for chunks of `units` rows / rays.  Workgroup b of the primary kernel appends to
-// sub-queue b mod n_sub and each of its (at most 256) pixels queues at most g children, which
+// sub-queue b mod n_sub and each of its rays (one per thread) queues at most g children, which
 // bounds the level-1 sub-queues; a bounce launch feeds every output sub-queue from exactly
-// ceil(cap_sub / 256) workgroups, which bounds the next level the same way.
+// ceil(cap_sub / kRayBlock) workgroups, which bounds the next level the same way.
 template <typename R>
 void size_queues(uint32_t sf, uint32_t levels, uint32_t hsize, uint64_t units, FramePlan *p)
 {
     const uint64_t g = children_per_hit(sf);
-    const uint64_t blocks0 = hsize ? camera_blocks(sf, hsize, units) : (units + kBlock - 1) / kBlock;
+    const uint64_t blocks0 = hsize ? camera_blocks(sf, hsize, units) : (units + kRayBlock<R> - 1) / kRayBlock<R>;
     uint32_t n_sub = 1;
     while (n_sub < 256 && (uint64_t)n_sub * 2 * 8 <= blocks0) n_sub *= 2;
     p->levels = levels;
@@ -642,15 +642,15 @@ void size_queues(uint32_t sf, uint32_t levels, uint32_t hsize, uint64_t units, F
     p->chunk_units = units;
     p->odd_entries = p->even_entries = 0;
     for (auto &c : p->cap_sub) c = 0;
-    // pixels per primary workgroup: four 8x8 tiles of which only `units` rows exist when the
-    // chunk is lower than a tile
-    const uint64_t per_block0 = (hsize && (sf & SF_CULL) && units < 8) ? (kBlock / 8) * units : (uint64_t)kBlock;
+    // rays per primary workgroup: kRayBlock of a ray batch, kCamBlock pixels of a frame, of whose
+    // 8x8 tiles only `units` rows exist when the chunk is lower than a tile
+    const uint64_t per_block0 = !hsize ? (uint64_t)kRayBlock<R> : ((sf & SF_CULL) && units < 8) ? (kCamBlock / 8) * units : (uint64_t)kCamBlock;
     uint64_t cap = ((blocks0 + n_sub - 1) / n_sub) * per_block0 * g;
     for (uint32_t L = 1; L <= levels; ++L) {
         p->cap_sub[L] = cap;
         uint64_t &tot = (L & 1) ? p->odd_entries : p->even_entries;
         tot = std::max(tot, cap * n_sub);
-        cap = ((cap + kBlock - 1) / kBlock) * kBlock * g;
+        cap = ((cap + kRayBlock<R> - 1) / kRayBlock<R>) * kRayBlock<R> * g;
     }
     p->bytes = (size_t)((p->odd_entries + p->even_entries) * 8 * sizeof(R));
 }
