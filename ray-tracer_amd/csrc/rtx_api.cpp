@@ -69,8 +69,35 @@ struct Slot {
     hipEvent_t done = nullptr;  // recorded when a call returns with work still in flight
     bool pending = false;
     bool busy = false;
+    hipStream_t active = nullptr;  // stream this call may have queued work on that nothing has waited for yet
+    bool has_active = false;
     char *pin[2] = { nullptr, nullptr };  // pinned staging buffers for large copies to pageable memory
     hipEvent_t pin_ev[2] = { nullptr, nullptr };
+
+    // Give everything back to the runtime (the slot's device must be current).
+    void release()
+    {
+        if (stream) (void)hipStreamSynchronize(stream);
+        for (void *p : { queues, fb, aux, prim, (void *)counts, (void *)shards })
+            if (p) (void)hipFree(p);
+        queues = fb = aux = prim = nullptr;
+        counts = nullptr;
+        shards = nullptr;
+        if (done) (void)hipEventDestroy(done);
+        done = nullptr;
+        for (int k = 0; k < 2; ++k) {
+            if (pin[k]) (void)hipHostFree(pin[k]);
+            if (pin_ev[k]) (void)hipEventDestroy(pin_ev[k]);
+            pin[k] = nullptr;
+            pin_ev[k] = nullptr;
+        }
+        for (auto &e : ev) {
+            if (e) (void)hipEventDestroy(e);
+            e = nullptr;
+        }
+        if (stream) (void)hipStreamDestroy(stream);
+        stream = nullptr;
+    }
 };
 
 }  // namespace
@@ -122,10 +149,18 @@ int slot_acquire(rtx_context *ctx, Slot **out)
             return RTX_OK;
         }
     std::unique_ptr<Slot> s(new Slot);
-    HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-    for (auto &e : s->ev) HIP_TRY(hipEventCreate(&e));
-    HIP_TRY(hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
-    HIP_TRY(hipMalloc((void **)&s->shards, sizeof(StatShard) * kStatShards));
+    auto build = [&]() -> int {
+        HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+        for (auto &e : s->ev) HIP_TRY(hipEventCreate(&e));
+        HIP_TRY(hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
+        HIP_TRY(hipMalloc((void **)&s->shards, sizeof(StatShard) * kStatShards));
+        return RTX_OK;
+    };
+    const int rc = build();
+    if (rc) {
+        s->release();  // what a half-built slot holds
+        return rc;
+    }
     s->busy = true;
     *out = s.get();
     ctx->slots.push_back(std::move(s));
@@ -142,7 +177,12 @@ struct SlotLease {
     explicit SlotLease(rtx_context *c) : ctx(c) {}
     ~SlotLease()
     {
-        if (slot) slot_release(ctx, slot);
+        if (!slot) return;
+        // A call that fails half-way may leave kernels running on the slot's scratch memory: the
+        // next user of the slot must wait for them like for any work left in flight.
+        if (slot->has_active && hipEventRecord(slot->done, slot->active) == hipSuccess) slot->pending = true;
+        slot->has_active = false;
+        slot_release(ctx, slot);
     }
 };
 
@@ -154,8 +194,12 @@ int slot_order_after_pending(Slot *slot, hipStream_t stream)
         HIP_TRY(hipStreamWaitEvent(stream, slot->done, 0));
         slot->pending = false;
     }
+    slot->active = stream;
+    slot->has_active = true;
     return RTX_OK;
 }
+// Everything the call queued has been waited for (or handed over through slot->done).
+void slot_settled(Slot *slot) { slot->has_active = false; }
 
 int grow(void **ptr, size_t *have, size_t need)
 {
@@ -859,6 +903,7 @@ int render_impl(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_desc 
     if (!sync) {
         HIP_TRY(hipEventRecord(slot->done, stream));
         slot->pending = true;
+        slot_settled(slot);
         return RTX_OK;
     }
     if (host_out && channels8) {
@@ -873,6 +918,7 @@ int render_impl(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_desc 
         if (rc) return rc;
     }
     HIP_TRY(hipStreamSynchronize(stream));
+    slot_settled(slot);
     rc = collect_stats(slot, n_chunks, n_pix, true, stats);
     if (rc) return rc;
     if (stats) {
@@ -917,6 +963,7 @@ int trace_impl(rtx_context *ctx, const rtx_scene *scene, const double *rays, siz
     }
     HIP_TRY(hipMemcpyAsync(dst, slot->fb, n * 3 * sizeof(R), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    slot_settled(slot);
     if (sizeof(R) != sizeof(double))
         for (size_t i = 0; i < n * 3; ++i) out_rgb[i] = (double)tmp[i];
     rc = collect_stats(slot, n_chunks, n, true, stats);
@@ -975,23 +1022,7 @@ void rtx_context_destroy(rtx_context *ctx)
     if (!ctx) return;
     {
         DeviceGuard guard(ctx->device);
-        for (auto &s : ctx->slots) {
-            if (s->stream) (void)hipStreamSynchronize(s->stream);
-            if (s->queues) (void)hipFree(s->queues);
-            if (s->fb) (void)hipFree(s->fb);
-            if (s->aux) (void)hipFree(s->aux);
-            if (s->prim) (void)hipFree(s->prim);
-            if (s->counts) (void)hipFree(s->counts);
-            if (s->shards) (void)hipFree(s->shards);
-            if (s->done) (void)hipEventDestroy(s->done);
-            for (int k = 0; k < 2; ++k) {
-                if (s->pin[k]) (void)hipHostFree(s->pin[k]);
-                if (s->pin_ev[k]) (void)hipEventDestroy(s->pin_ev[k]);
-            }
-            for (auto &e : s->ev)
-                if (e) (void)hipEventDestroy(e);
-            if (s->stream) (void)hipStreamDestroy(s->stream);
-        }
+        for (auto &s : ctx->slots) s->release();
     }
     delete ctx;
 }
@@ -1202,6 +1233,7 @@ int rtx_probe_rays(rtx_context *ctx, const rtx_scene *scene, const double *rays,
     HIP_TRY(launch_probe(scene->sf, grid_for(ctx, n), slot->stream, scene->dev64, (const double *)slot->aux, (uint32_t)n, d_out));
     HIP_TRY(hipMemcpyAsync(out, d_out, n * sizeof(rtx_probe), hipMemcpyDeviceToHost, slot->stream));
     HIP_TRY(hipStreamSynchronize(slot->stream));
+    slot_settled(slot);
     return RTX_OK;
 }
 
@@ -1224,6 +1256,7 @@ int rtx_selfcheck_division(rtx_context *ctx, uint64_t seed, uint32_t n, int narr
     unsigned long long count = 0;
     HIP_TRY(hipMemcpyAsync(&count, slot->aux, sizeof count, hipMemcpyDeviceToHost, slot->stream));
     HIP_TRY(hipStreamSynchronize(slot->stream));
+    slot_settled(slot);
     *mismatches = count;
     return RTX_OK;
 }
@@ -1250,6 +1283,7 @@ int rtx_generate_rays(rtx_context *ctx, const rtx_camera_desc *camera, uint64_t 
     HIP_TRY(Launch<double>::raygen(grid_for(ctx, n), slot->stream, cd, (uint32_t)first_pixel, (uint32_t)n, (double *)slot->aux));
     HIP_TRY(hipMemcpyAsync(out, slot->aux, n * 6 * sizeof(double), hipMemcpyDeviceToHost, slot->stream));
     HIP_TRY(hipStreamSynchronize(slot->stream));
+    slot_settled(slot);
     return RTX_OK;
 }
 
