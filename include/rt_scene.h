@@ -47,7 +47,9 @@ int rt_mat4_invert(const double *a, double *out);
 void rt_mat4_mul_tuple(const double *m, const double *tup4, double *out4);
 int rt_view_transform(const double *from3, const double *to3, const double *up3, double *out);
 
-/* src/shapes/objects.rs:36-52 and the constructors of spheres.rs .. cones.rs */
+/* src/shapes/objects.rs:36-52 and the constructors of spheres.rs .. cones.rs; NULL (and a message
+ * in rt_last_panic) for a shape that is not 0..4 (sphere, plane, cube,
+ * cylinder, cone: the RTX_* shape tags of rtx.h) */
 rt_object *rt_object_new(int shape, double ymin, double ymax, int closed);
 rt_object *rt_glass_sphere(void); /* src/shapes/spheres.rs:7-19 */
 rt_object *rt_object_clone(const rt_object *o);

@@ -69,6 +69,10 @@ int rt_view_transform(const double *f, const double *t, const double *u, double 
 
 rt_object *rt_object_new(int shape, double ymin, double ymax, int closed)
 {
+    if (shape < (int)ShapeKind::Sphere || shape > (int)ShapeKind::Cone) {
+        tl_panic = "unknown shape " + std::to_string(shape);
+        return nullptr;
+    }
     Shape s;
     s.kind = (ShapeKind)shape;
     if (s.kind == ShapeKind::Cylinder || s.kind == ShapeKind::Cone) {

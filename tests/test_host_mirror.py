@@ -176,3 +176,11 @@ def test_scene_generators_are_deterministic(orc):
     # SplitMix64 reference vector (seed 1234567)
     rng = scenes.SplitMix64(1234567)
     assert [rng.next_u64() for _ in range(3)] == [6457827717110365317, 3203168211198807973, 9817491932198370423]
+
+
+def test_unknown_shape_is_refused(rta):
+    """rt_object_new hands out no object for a shape tag outside sphere .. cone."""
+    api = rta.api
+    assert not api.object_new(5, 0.0, 0.0, 0)
+    assert not api.object_new(-1, 0.0, 0.0, 0)
+    assert b"unknown shape" in api.last_panic()
