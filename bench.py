@@ -214,6 +214,16 @@ def main():
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1) / args.steps
 
+    # the same loop without the gather: what the tiles alone cost (reported beside the step time, not as it)
+    render_only_wall = None
+    if distributed:
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            rta.render_device(ctx, scene, cd, args.depth, prec, r0, r1, tile.data_ptr(), tile.numel() * tile.element_size(), stream)
+        fence()
+        render_only_wall = time.perf_counter() - t1
+
     # average device time of the dominant kernel (HIP events around it on its own stream)
     k_primary, k_all = [], []
     for _ in range(min(args.steps, 50)):
@@ -234,13 +244,15 @@ def main():
         rta._check(rta.rtx_render_8bit(ctx.h, scene.h, cd, args.depth, prec, r0, r1, 4, rgba.ctypes.data, rgba.nbytes, None, None, None))
         host_rgba8_ms = min(host_rgba8_ms, (time.perf_counter() - t_h) * 1e3)
 
-    vals = torch.tensor([wall, float(st["color_rays"]), float(st["shadow_rays"])], dtype=torch.float64, device="cuda")
+    vals = torch.tensor([wall, float(st["color_rays"]), float(st["shadow_rays"]), render_only_wall or 0.0], dtype=torch.float64,
+                        device="cuda")
     if distributed:
         mx = vals.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = vals.clone()
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         wall = float(mx[0])
+        render_only_wall = float(mx[3])
         color_rays, shadow_rays = int(sm[1]), int(sm[2])
     else:
         color_rays, shadow_rays = st["color_rays"], st["shadow_rays"]
@@ -301,6 +313,11 @@ def main():
                 "launches_per_frame": st["n_launches"],
             },
         }
+        if distributed:
+            # slowest rank's tile without the gather, and the frame bytes the gather moves to rank 0
+            out["frame"]["render_only_ms"] = render_only_wall * 1e3 / args.steps
+            out["frame"]["render_only_Mrays_per_s"] = rays / (render_only_wall / args.steps) / 1e6
+            out["frame"]["gather_bytes"] = args.height * args.width * 3 * tile.element_size() * (n_gpus - 1) // max(n_gpus, 1)
         if not args.no_cpu_baseline and n_gpus == 1:
             out["cpu_baseline"] = cpu_baseline(args.scene, args.width, args.height, args.depth, args.objects, args.cpu_seconds)
         if not args.no_extra and n_gpus == 1 and args.scene == "default" and args.precision == "f64":
