@@ -348,7 +348,8 @@ def test_bounding_sphere_tests_change_nothing(orc, rta):
 def test_8bit_output_matches_the_reference_conversion(orc, rta):
     """rtx_render_8bit = render + `(c * 255.999) as u8` on the device (src/scenes/canvas.rs:80-104):
     identical to converting the f64 frame on the host; RGBA carries alpha 255; partial row ranges
-    and the f32 path work too."""
+    and the f32 path work too.  (On these 6 000-pixel frames a handful of pixels where a checker
+    plane meets the horizon decide the fast path's share, hence the loose last bound here.)"""
     from ray_tracer_amd import scenes
     ctx = rta.Context()
     for fn, kw in [(scenes.default_scene, dict(hsize=131, vsize=77)), (scenes.spheres_on_plane, dict(hsize=96, vsize=54)),
@@ -376,7 +377,14 @@ def test_8bit_output_matches_the_reference_conversion(orc, rta):
         assert np.array_equal(part, want[10:H - 3])
         f32 = np.zeros((H, W, 4), dtype=np.uint8)
         rta._check(rta.rtx_render_8bit(ctx.h, scene.h, cd, 5, rta.F32, 0, H, 4, f32.ctypes.data, f32.nbytes, None, None, None))
-        assert (np.abs(f32[:, :, :3].astype(int) - want.astype(int)).max(axis=2) <= 1).mean() >= 0.999
+        # the conversion is the same in the fast path: the bytes are those of its own float frame (how
+        # close that frame is to the f64 one is test_f32_fast_path's subject)
+        f32_frame = np.empty((H, W, 3), dtype=np.float32)
+        rta._check(rta.rtx_render(ctx.h, scene.h, cd, 5, rta.F32, 0, H, f32_frame.ctypes.data, f32_frame.nbytes, None, None, None))
+        v = f32_frame * np.float32(255.999)
+        f32_want = np.where(np.isnan(v) | (v <= 0), 0, np.where(v >= 255, 255, np.trunc(v))).astype(np.uint8)
+        assert np.array_equal(f32[:, :, :3], f32_want) and (f32[:, :, 3] == 255).all()
+        assert (np.abs(f32[:, :, :3].astype(int) - want.astype(int)).max(axis=2) <= 1).mean() >= 0.995
         with pytest.raises(rta.RtxError):
             rta._check(rta.rtx_render_8bit(ctx.h, scene.h, cd, 5, rta.F64, 0, H, 2, got.ctypes.data, got.nbytes, None, None, None))
         with pytest.raises(rta.RtxError):

@@ -5,9 +5,10 @@ import re, subprocess, sys
 
 prec = sys.argv[1] if len(sys.argv) > 1 else "f64"
 contract = "off" if prec == "f64" else "fast"
+extra = [] if prec == "f64" else ["-fno-slp-vectorize"]  # as build.sh compiles the f32 kernels
 asm = "/tmp/render_%s.s" % prec
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=" + contract,
-                "--cuda-device-only", "-S", "-o", asm, "ray-tracer_amd/csrc/render_%s.hip" % prec] + sys.argv[2:],
+                "--cuda-device-only", "-S", "-o", asm, "ray-tracer_amd/csrc/render_%s.hip" % prec] + extra + sys.argv[2:],
                check=True, stderr=subprocess.DEVNULL)
 s = open(asm).read()
 meta = {}
