@@ -208,13 +208,14 @@ typedef struct rtx_probe {
 int rtx_probe_rays(rtx_context *ctx, const rtx_scene *scene, const double *rays, size_t n, rtx_probe *out);
 
 /*
- * Self-check of the f64 kernels' division shortcut.  The reference divides a vector by its
- * magnitude component by component (Tuple::normalize, src/matrices/tuples.rs:58-73); the kernels
- * share the refined reciprocal of the divisor between the three quotients and must still produce
- * the bits of three separate IEEE divisions.  Runs both on n pseudo-random operand sets (narrow
- * != 0: exponents near 0, where the shortcut is taken; narrow == 0: the whole f64 range with
- * zeros, infinities, NaNs and denormals) and returns in *mismatches the number of sets that
- * differ.  Anything but 0 is a bug.
+ * Self-check of the f64 kernels' division and square-root shortcuts.  The reference divides a
+ * vector by its magnitude component by component (Tuple::normalize, src/matrices/tuples.rs:58-73)
+ * and takes f64::sqrt in many places; the kernels share the refined reciprocal of a divisor
+ * between quotients and skip the range handling of the expanded square root when the operand
+ * allows, and must still produce the bits of separate IEEE divisions and roots.  Runs both ways
+ * on n pseudo-random operand sets (narrow != 0: exponents near 0, where the shortcuts are taken;
+ * narrow == 0: the whole f64 range with zeros, infinities, NaNs and denormals) and returns in
+ * *mismatches the number of sets that differ.  Anything but 0 is a bug.
  */
 int rtx_selfcheck_division(rtx_context *ctx, uint64_t seed, uint32_t n, int narrow, uint64_t *mismatches);
 

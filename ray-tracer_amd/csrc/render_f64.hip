@@ -51,8 +51,9 @@ hipError_t launch_probe(uint32_t sf, uint32_t grid, hipStream_t stream, const Sc
     return hipGetLastError();
 }
 
-// Self-check of div3 against the plain divisions on n pseudo-random operand sets: exponents over
-// the whole f64 range (so both branches run), zeros, infinities, NaNs and denormals among them.
+// Self-check of div3, the square root and the fused normalisation against the compiler's plain
+// divisions and roots on n pseudo-random operand sets: exponents over the whole f64 range (so
+// both branches run), zeros, infinities, NaNs and denormals among them.
 // Counts the sets where any quotient differs in its bits (NaNs compare as equal to NaNs).
 __global__ void __launch_bounds__(kBlock)
 k_check_div3(uint64_t seed, uint32_t n, uint32_t narrow, unsigned long long *mismatches)
@@ -87,6 +88,20 @@ k_check_div3(uint64_t seed, uint32_t n, uint32_t narrow, unsigned long long *mis
     for (int i = 0; i < 3; ++i) {
         const bool both_nan = want[i] != want[i] && got[i] != got[i];
         bad = bad || (!both_nan && __builtin_bit_cast(uint64_t, want[i]) != __builtin_bit_cast(uint64_t, got[i]));
+    }
+    // the square root with and without its range handling, and the fused a / |a|
+    const double x = __builtin_fabs(b);
+    const double root = Num<double>::sqrt_(x), root_want = __builtin_sqrt(x);
+    bad = bad || (!(root != root && root_want != root_want) && __builtin_bit_cast(uint64_t, root) != __builtin_bit_cast(uint64_t, root_want));
+    const double neg_root = Num<double>::sqrt_(-x);  // NaN, or -0 for -0
+    bad = bad || (x != 0.0 && neg_root == neg_root);
+    const double m2 = (a.x * a.x + a.y * a.y) + a.z * a.z;
+    const V3<double> u = normalized(a, m2);
+    const double mag = __builtin_sqrt(m2);
+    const double u_want[3] = { a.x / mag, a.y / mag, a.z / mag }, u_got[3] = { u.x, u.y, u.z };
+    for (int i = 0; i < 3; ++i) {
+        const bool both_nan = u_want[i] != u_want[i] && u_got[i] != u_got[i];
+        bad = bad || (!both_nan && __builtin_bit_cast(uint64_t, u_want[i]) != __builtin_bit_cast(uint64_t, u_got[i]));
     }
     if (bad) atomicAdd(mismatches, 1ull);
 }

@@ -34,7 +34,7 @@ template <> struct Num<double> {
     static constexpr double eps = 0.00001;                   // src/utils.rs:1
     static constexpr double big = 1.7976931348623157e308;    // f64::MAX
     static constexpr double inf = __builtin_huge_val();
-    static RT_DEV double sqrt_(double x) { return __builtin_sqrt(x); }
+    static RT_DEV double sqrt_(double x);  // below: the compiler's sequence without its range handling when x allows
     static RT_DEV double div(double a, double b) { return a / b; }
     static RT_DEV double pow_(double a, double b) { return pow(a, b); }
     static RT_DEV double abs_(double x) { return __builtin_fabs(x); }
@@ -88,16 +88,55 @@ RT_DEV double quotient_with(double a, double b, double r)
     const double m = a * r;
     return __builtin_fma(__builtin_fma(-b, m, a), r, m);
 }
-RT_DEV V3<double> div3(V3<double> a, double b)
+RT_DEV uint32_t high_word(double v) { return (uint32_t)(__builtin_bit_cast(uint64_t, v) >> 32); }
+RT_DEV void exponent_range(V3<double> a, uint32_t &lo, uint32_t &hi)
 {
     const uint32_t ex = exponent_bits(a.x), ey = exponent_bits(a.y), ez = exponent_bits(a.z);
-    const uint32_t lo = ex < ey ? (ex < ez ? ex : ez) : (ey < ez ? ey : ez);
-    const uint32_t hi = ex > ey ? (ex > ez ? ex : ez) : (ey > ez ? ey : ez);
+    lo = ex < ey ? (ex < ez ? ex : ez) : (ey < ez ? ey : ez);
+    hi = ex > ey ? (ex > ez ? ex : ez) : (ey > ez ? ey : ez);
+}
+RT_DEV V3<double> div3(V3<double> a, double b)
+{
+    uint32_t lo, hi;
+    exponent_range(a, lo, hi);
     if (lo >= kDivLo && hi < kDivHi && ordinary(exponent_bits(b))) {
         const double r = refined_rcp(b);
         return { quotient_with(a.x, b, r), quotient_with(a.y, b, r), quotient_with(a.z, b, r) };
     }
     return { a.x / b, a.y / b, a.z / b };
+}
+// The square root is expanded the same way: the operand is scaled by 2^256 when it is below
+// 2^-767, y = rsq(x) is refined by the ten operations below, the result is scaled back, and zeros
+// and +infinity pass through.  For a positive x with an exponent in [-600, 600] only the ten
+// operations act; they give the bits of the full sequence (a correctly rounded root, as the
+// reference's f64::sqrt is).
+constexpr uint32_t kSqrtLo = (1023u - 600u) << 20, kSqrtHi = (1023u + 600u) << 20;
+RT_DEV bool ordinary_radicand(double x) { return high_word(x) - kSqrtLo < kSqrtHi - kSqrtLo; }  // false for x < 0 too
+RT_DEV double sqrt_steps(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+    return __builtin_fma(__builtin_fma(-g, g, x), h, g);
+}
+RT_DEV double Num<double>::sqrt_(double x) { return ordinary_radicand(x) ? sqrt_steps(x) : __builtin_sqrt(x); }
+// a / |a| (src/matrices/tuples.rs:58-73) with one range check for the root and the quotients: a
+// squared magnitude with an exponent in [-600, 600] has a root that is ordinary for the division
+RT_DEV V3<double> normalized(V3<double> a, double m2)
+{
+    uint32_t lo, hi;
+    exponent_range(a, lo, hi);
+    if (ordinary_radicand(m2) && lo >= kDivLo && hi < kDivHi) {
+        const double mag = sqrt_steps(m2);
+        const double r = refined_rcp(mag);
+        return { quotient_with(a.x, mag, r), quotient_with(a.y, mag, r), quotient_with(a.z, mag, r) };
+    }
+    const double mag = __builtin_sqrt(m2);
+    return { a.x / mag, a.y / mag, a.z / mag };
 }
 RT_DEV V3<float> div3(V3<float> a, float b)
 {
@@ -112,8 +151,7 @@ template <typename R> RT_DEV V3<R> normalize3(V3<R> a)
 {
     const R m2 = (a.x * a.x + a.y * a.y) + a.z * a.z;
     if constexpr (Num<R>::exact) {
-        const R mag = Num<R>::sqrt_(m2);
-        return div3(a, mag);
+        return normalized(a, m2);
     } else {
         const R r = __builtin_amdgcn_rsqf(m2);
         return { a.x * r, a.y * r, a.z * r };
