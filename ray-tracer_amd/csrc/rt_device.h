@@ -126,17 +126,25 @@ RT_DEV double sqrt_steps(double x)
 RT_DEV double Num<double>::sqrt_(double x) { return ordinary_radicand(x) ? sqrt_steps(x) : __builtin_sqrt(x); }
 // a / |a| (src/matrices/tuples.rs:58-73) with one range check for the root and the quotients: a
 // squared magnitude with an exponent in [-600, 600] has a root that is ordinary for the division
-RT_DEV V3<double> normalized(V3<double> a, double m2)
+RT_DEV V3<double> normalized(V3<double> a, double m2, double *length = nullptr)
 {
     uint32_t lo, hi;
     exponent_range(a, lo, hi);
     if (ordinary_radicand(m2) && lo >= kDivLo && hi < kDivHi) {
         const double mag = sqrt_steps(m2);
+        if (length) *length = mag;
         const double r = refined_rcp(mag);
         return { quotient_with(a.x, mag, r), quotient_with(a.y, mag, r), quotient_with(a.z, mag, r) };
     }
     const double mag = __builtin_sqrt(m2);
+    if (length) *length = mag;
     return { a.x / mag, a.y / mag, a.z / mag };
+}
+RT_DEV V3<float> normalized(V3<float> a, float m2, float *length = nullptr)
+{
+    const float r = __builtin_amdgcn_rsqf(m2);
+    if (length) *length = m2 * r;
+    return { a.x * r, a.y * r, a.z * r };
 }
 RT_DEV V3<float> div3(V3<float> a, float b)
 {
@@ -954,8 +962,8 @@ RT_DEV Node<R> trace_node(const SceneDev<R> &S, const PrimScene<R> *P, V3<R> ro,
     // shade_hit, world.rs:121-123.  is_shadowed (world.rs:146-150) and lighting (lights.rs:49)
     // both normalise light.position - over_point; the vector is formed once here.
     V3<R> lvec = { S.light_pos[0] - over.x, S.light_pos[1] - over.y, S.light_pos[2] - over.z };
-    R ldist = Num<R>::sqrt_((lvec.x * lvec.x + lvec.y * lvec.y) + lvec.z * lvec.z);
-    V3<R> lightv = div3(lvec, ldist);
+    R ldist;
+    V3<R> lightv = normalized(lvec, (lvec.x * lvec.x + lvec.y * lvec.y) + lvec.z * lvec.z, &ldist);
     bool shadowed = is_shadowed<R, SF>(S, over, lightv, ldist);
     nd.shadowed = shadowed;
 
