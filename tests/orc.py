@@ -8,7 +8,8 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(ROOT, "oracle", "liboracle.so")
+# ORC_LIB: another build of the same source (the operation-counting one of tools/flop_check.py)
+LIB_PATH = os.environ.get("ORC_LIB") or os.path.join(ROOT, "oracle", "liboracle.so")
 
 sys.path.insert(0, ROOT)
 import __graft_entry__ as _entry  # noqa: E402
