@@ -6,6 +6,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -60,8 +61,11 @@ struct Slot {
     size_t fb_bytes = 0;
     void *aux = nullptr;        // ray upload / probe output
     size_t aux_bytes = 0;
-    void *prim = nullptr;       // per-frame primary-ray tables
+    void *prim = nullptr;       // primary-ray tables of the scene and camera origin below
     size_t prim_bytes = 0;
+    uint64_t prim_scene = 0;    // rtx_scene::serial the tables were built from (0: none)
+    double prim_origin[3] = { 0, 0, 0 };
+    size_t prim_elem = 0;       // sizeof(R) of the tables
     uint32_t *counts = nullptr; // sub-queue length counters: per chunk, per level, per sub-queue
     size_t counts_n = 0;
     uint32_t n_sub = 1;         // sub-queues per queue of the last frame enqueued
@@ -116,6 +120,7 @@ struct rtx_context {
 
 struct rtx_scene {
     rtx_context *ctx = nullptr;
+    uint64_t serial = 0;  // unique per upload: identifies the tables that derived data was built from
     uint32_t n = 0;
     uint32_t sf = 0;
     void *blob64 = nullptr, *blob32 = nullptr;  // device tables, one allocation per precision
@@ -764,8 +769,10 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Slot *slot, hipStrea
         const size_t b_sph = pad(SD.n_sph * sizeof(PrimSphereRec<R>)), b_pln = pad(SD.n_pln * sizeof(PrimPlaneRec<R>)),
                      b_cub = pad(SD.n_cub * sizeof(PrimCubeRec<R>)), b_cyl = pad(SD.n_cyl * sizeof(PrimCappedRec<R>)),
                      b_con = pad(SD.n_con * sizeof(PrimCappedRec<R>));
+        const void *before = slot->prim;
         rc = grow(&slot->prim, &slot->prim_bytes, b_sph + b_pln + b_cub + b_cyl + b_con + 256);
         if (rc) return rc;
+        if (slot->prim != before) slot->prim_scene = 0;
         char *base = (char *)slot->prim;
         prim.sph = (const PrimSphereRec<R> *)base;
         prim.pln = (const PrimPlaneRec<R> *)(base + b_sph);
@@ -774,8 +781,23 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Slot *slot, hipStrea
         prim.con = (const PrimCappedRec<R> *)(base + b_sph + b_pln + b_cub + b_cyl);
         prim.n_sph = SD.n_sph; prim.n_pln = SD.n_pln; prim.n_cub = SD.n_cub; prim.n_cyl = SD.n_cyl; prim.n_con = SD.n_con;
     }
-    HIP_TRY(Launch<R>::frame_begin(stream, cam, SD, prim, slot->counts, (uint32_t)counts_need, (uint32_t *)slot->shards,
-                                   (uint32_t)(sizeof(StatShard) * kStatShards / sizeof(uint32_t))));
+    // The first launch of a frame zeroes the queue and hit counters and fills the primary-ray tables.
+    // A frame with no secondary rays whose caller does not read the counters needs neither when the
+    // tables already hold this scene seen from this camera origin: rendering the same view again
+    // (or another row range of it) is then one launch.
+    const bool tables_current = cam && SD.n && slot->prim_scene == scene->serial && slot->prim_elem == sizeof(R) &&
+                                slot->prim_origin[0] == (double)cam->origin[0] && slot->prim_origin[1] == (double)cam->origin[1] &&
+                                slot->prim_origin[2] == (double)cam->origin[2];
+    const bool no_children = (scene->sf & (SF_REFLECTIVE | SF_TRANSPARENT)) == 0;  // nothing is ever queued
+    if (!(tables_current && no_children && plan.levels == 0 && !timed)) {
+        HIP_TRY(Launch<R>::frame_begin(stream, cam, SD, prim, slot->counts, (uint32_t)counts_need, (uint32_t *)slot->shards,
+                                       (uint32_t)(sizeof(StatShard) * kStatShards / sizeof(uint32_t))));
+        if (cam && SD.n) {
+            slot->prim_scene = scene->serial;
+            slot->prim_elem = sizeof(R);
+            for (int k = 0; k < 3; ++k) slot->prim_origin[k] = (double)cam->origin[k];
+        }
+    }
 
     R *q_odd = (R *)slot->queues;
     R *q_even = q_odd + plan.odd_entries * 8;
@@ -1104,6 +1126,8 @@ int rtx_scene_upload(rtx_context *ctx, const rtx_scene_desc *d, rtx_scene **out)
     DeviceGuard guard(ctx->device);
     if (!guard.ok) return fail(RTX_ERR_DEVICE, "hipSetDevice(%d) failed", ctx->device);
     std::unique_ptr<rtx_scene> s(new rtx_scene);
+    static std::atomic<uint64_t> next_serial{ 1 };
+    s->serial = next_serial.fetch_add(1);
     s->ctx = ctx;
     s->n = n;
     // Bounding-sphere tests cost about 20 instructions per object and ray: they pay once most

@@ -515,6 +515,86 @@ def test_calls_after_an_asynchronous_render_are_ordered(orc, rta):
         ctx.close()
 
 
+def test_repeated_views_reuse_the_primary_tables_correctly(orc, rta):
+    """A frame without secondary rays whose caller reads no counters skips the launch that refills
+    the per-camera tables when they already hold this scene seen from this origin.  Whatever comes
+    in between -- the camera moving, another scene, a ray batch, the other precision, a call that
+    asks for statistics -- every frame must be what a fresh synchronous render gives."""
+    import ctypes as C
+    from ray_tracer_amd import scenes
+    with open("/proc/self/maps") as f:
+        paths = sorted({line.split()[-1] for line in f if "libamdhip64.so" in line})
+    hip = C.CDLL(paths[0])
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipFree.argtypes = [C.c_void_p]
+    hip.hipDeviceSynchronize.argtypes = []
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    W, H = 200, 120
+    ctx = rta.Context()
+    ref_ctx = rta.Context()  # fresh synchronous renders come from a context of their own
+    api = rta.api
+
+    def view(frm):
+        cam = api.camera(W, H, math.pi / 2)
+        cam.set_view(frm, (0.0, 1.0, 0.0), (0.0, 1.0, 0.0))
+        return rta.camera_desc(cam)
+
+    worlds = [scenes.default_scene(api, W, H)[0], scenes.spheres_on_plane(api, W, H)[0]]
+    flats = [rta.flatten(w) for w in worlds]
+    sc = [rta.Scene(ctx, f) for f in flats]
+    ref_sc = [rta.Scene(ref_ctx, f) for f in flats]
+    views = [view((0.0, 1.5, -5.0)), view((1.0, 2.0, -4.0))]
+    d_buf = C.c_void_p()
+    nbytes = W * H * 3 * 8
+    assert hip.hipMalloc(C.byref(d_buf), nbytes) == 0
+
+    def fresh(si, vi, prec):
+        out = np.empty((H, W, 3), dtype=np.float64 if prec == rta.F64 else np.float32)
+        rta._check(rta.rtx_render(ref_ctx.h, ref_sc[si].h, views[vi], 5, prec, 0, H, out.ctypes.data, out.nbytes, None, None, None))
+        return out
+
+    def quiet(si, vi, prec, rows=(0, H)):
+        """asynchronous, no statistics: the path that may skip the table launch"""
+        elem = 8 if prec == rta.F64 else 4
+        assert hip.hipMemset(d_buf, 0xFF, nbytes) == 0
+        assert hip.hipDeviceSynchronize() == 0  # the fill is on the null stream, the render on a non-blocking one
+        rta.render_device(ctx, sc[si], views[vi], 5, prec, rows[0], rows[1], d_buf.value, (rows[1] - rows[0]) * W * 3 * elem, None)
+        assert hip.hipDeviceSynchronize() == 0
+        out = np.empty((rows[1] - rows[0], W, 3), dtype=np.float64 if prec == rta.F64 else np.float32)
+        assert hip.hipMemcpy(out.ctypes.data, d_buf, out.nbytes, 2) == 0
+        return out
+
+    try:
+        steps = [(0, 0, rta.F64), (0, 0, rta.F64), (0, 1, rta.F64), (0, 1, rta.F64), (1, 1, rta.F64), (0, 1, rta.F64),
+                 (0, 1, rta.F32), (0, 1, rta.F32), (0, 1, rta.F64), (0, 0, rta.F64)]
+        for k, (si, vi, prec) in enumerate(steps):
+            got, want = quiet(si, vi, prec), fresh(si, vi, prec)
+            assert np.array_equal(got, want), "step %d: %d values differ, %d are NaN" % (k, int((got != want).sum()), int(np.isnan(got).sum()))
+            if k == 3:  # a ray batch and a call with statistics in between
+                rays = np.ascontiguousarray(np.array([[0, 0, -5, 0, 0, 1.0]]))
+                cols = np.empty((1, 3))
+                rta._check(rta.rtx_trace_rays(ctx.h, sc[0].h, rays.ctypes.data_as(rta._dp), 1, 5, rta.F64, cols.ctypes.data_as(rta._dp), None))
+                st = {}
+                rta.render_device(ctx, sc[0], views[1], 5, rta.F64, 0, H, d_buf.value, nbytes, None, st)
+                assert st["color_rays"] == W * H
+        # a row range of the view the tables hold
+        assert np.array_equal(quiet(0, 0, rta.F64, rows=(30, 77)), fresh(0, 0, rta.F64)[30:77])
+        # statistics are right after many quiet frames (the counters are cleared by the call that reads them)
+        st = {}
+        rta.render_device(ctx, sc[0], views[0], 5, rta.F64, 0, H, d_buf.value, nbytes, None, st)
+        want = {}
+        rta.render_device(ref_ctx, ref_sc[0], views[0], 5, rta.F64, 0, H, d_buf.value, nbytes, None, want)
+        assert (st["color_rays"], st["shadow_rays"]) == (want["color_rays"], want["shadow_rays"])
+    finally:
+        hip.hipFree(d_buf)
+        for s_ in sc + ref_sc:
+            s_.close()
+        ctx.close()
+        ref_ctx.close()
+
+
+
 def test_full_size_frame_properties(orc, rta):
     """BASELINE size (3840x2160, default world): a random sample of pixels against the oracle's
     color_at for the same primary rays, the ray counters against geometry, and the frame
