@@ -115,3 +115,12 @@ hipError_t launch_check_div3(hipStream_t stream, uint64_t seed, uint32_t n, uint
 template struct Launch<double>;
 
 }  // namespace rtx
+
+#ifdef RTX_COUNT_WALK
+extern "C" int rtx_debug_walk(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rtx::g_walk), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(rtx::g_walk), z, sizeof z) != hipSuccess) return -1; }
+    return 0;
+}
+#endif

@@ -429,6 +429,15 @@ RT_DEV bool may_hit(const BoundRec<R> &b, const CullRay<R> &cr, R reach)
 // before the launch and never by a kernel that walks them.  The other waves of the SIMD cover
 // the fetch latency.  keep(slot) says whether this lane's ray can hit the object at all; the
 // record is fetched only when some lane's can.
+
+// Diagnostic build (-DRTX_COUNT_WALK, tools/walk_count.py): counts group, cluster and object fetches
+// and exact intersections of the bounding-sphere walk, one count per wave and step.
+#ifdef RTX_COUNT_WALK
+static __device__ unsigned long long g_walk[8];
+#define RTX_WALK_COUNT(k) do { if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) atomicAdd(&g_walk[k], 1ull); } while (0)
+#else
+#define RTX_WALK_COUNT(k) do {} while (0)
+#endif
 #define RT_CONSTANT_AS __attribute__((address_space(4)))
 template <typename Rec> RT_DEV Rec load_uniform(const Rec *p)
 {
@@ -450,11 +459,13 @@ RT_DEV void walk_table(const Rec *recs, uint32_t n, uint32_t slot0, uint32_t clu
         static_assert(kCluster % 4 == 0, "spheres are fetched in fours");
         const uint32_t n_cl = (n + kCluster - 1) / kCluster;
         for (uint32_t g = group0, c0 = 0; c0 < n_cl; ++g, c0 += kCluster) {
+            RTX_WALK_COUNT(0);
             const bool kg = keep.group(g);
             if (__ballot(kg) == 0ull) continue;
             const uint32_t c1 = (c0 + kCluster < n_cl) ? c0 + kCluster : n_cl;
             for (uint32_t cb = c0; cb < c1; cb += 4) {
                 bool kc4[4];
+                RTX_WALK_COUNT(1);
                 keep.cluster4(cluster0 + cb, kg, kc4);
                 for (uint32_t j = 0; j < 4; ++j) {
                     const uint32_t c = cb + j;
@@ -463,10 +474,12 @@ RT_DEV void walk_table(const Rec *recs, uint32_t n, uint32_t slot0, uint32_t clu
                     const uint32_t i1 = (i0 + kCluster < n) ? i0 + kCluster : n;
                     for (uint32_t ib = i0; ib < i1; ib += 4) {
                         bool ko4[4];
+                        RTX_WALK_COUNT(2);
                         keep.object4(slot0 + ib, kc4[j], ko4);
                         for (uint32_t e = 0; e < 4; ++e) {
                             const uint32_t i = ib + e;
                             if (i >= i1 || __ballot(ko4[e]) == 0ull) continue;
+                            RTX_WALK_COUNT(3);
                             const Rec rec = load_uniform(recs + i);
                             if (ko4[e]) body(rec, slot0 + i);
                         }

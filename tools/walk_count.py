@@ -1,5 +1,6 @@
-"""Counts the steps of the bounding-sphere walk (a library built with -DRTX_COUNT_WALK):
-RTX_LIB=... python3 tools/walk_count.py [hsize] [vsize]"""
+"""Counts the steps of the bounding-sphere walk per camera wave.  Needs a library built with the
+counters:  RTX_LIBNAME=librtx_count.so RTX_HIP_FLAGS=-DRTX_COUNT_WALK ./build.sh lib
+then, on a GPU box:  RTX_LIB=$PWD/ray-tracer_amd/lib/librtx_count.so python3 tools/walk_count.py [hsize] [vsize]"""
 import ctypes, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
