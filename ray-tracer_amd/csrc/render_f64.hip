@@ -116,6 +116,14 @@ template struct Launch<double>;
 
 }  // namespace rtx
 
+#ifdef RTX_PHASE_CLOCK
+extern "C" int rtx_debug_phase(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rtx::g_phase), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(rtx::g_phase), z, sizeof z) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 #ifdef RTX_COUNT_WALK
 extern "C" int rtx_debug_walk(unsigned long long *out, int reset)
 {

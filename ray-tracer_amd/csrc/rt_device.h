@@ -180,7 +180,9 @@ template <typename R> RT_DEV V3<R> xform_vector(const R *m, V3<R> v)
 }
 
 // ---- ray/object intersection in object space -----------------------------------------
-// Each routine calls emit(t) once per intersection, in the order the reference pushes them.
+// Each routine calls emit(t) once per intersection, in the order the reference pushes them;
+// emit(t, ok) stands for `if (ok) emit(t)` where the condition is cheap (the callers fold it into
+// their selects instead of branching around a handful of instructions).
 // Terms that depend on the ray origin alone (`c` of the quadratics, the slab numerators of
 // the cube) come in as arguments: a secondary ray computes them per lane, while primary rays
 // -- which all start at the camera -- read them from a table built once per frame.
@@ -217,7 +219,7 @@ template <typename R, typename Emit> RT_DEV void isect_sphere(V3<R> o, V3<R> d, 
 // src/shapes/planes.rs:11-17; neg_oy = -origin.y
 template <typename R, typename Emit> RT_DEV void isect_plane(R neg_oy, R dy, Emit &&emit)
 {
-    if (!(Num<R>::abs_(dy) < Num<R>::eps)) emit(Num<R>::div(neg_oy, dy));
+    emit(Num<R>::div(neg_oy, dy), !(Num<R>::abs_(dy) < Num<R>::eps));  // a quotient by (nearly) zero is computed and dropped
 }
 // src/shapes/cubes.rs:31-51; lo_num = -1 - origin, hi_num = 1 - origin
 template <typename R> RT_DEV void cube_axis(R lo_num, R hi_num, R direction, R &tmin, R &tmax)
@@ -259,14 +261,14 @@ RT_DEV void isect_caps(V3<R> o, V3<R> d, R ymin, R ymax, bool closed, Emit &&emi
         R x = o.x + (t1 * d.x);
         R z = o.z + (t1 * d.z);
         R lim = CONE ? Num<R>::abs_(ymin) : R(1);
-        if (x * x + z * z <= lim) emit(t1);
+        emit(t1, x * x + z * z <= lim);
     }
     R t2 = Num<R>::div(ymax - o.y, d.y);
     {
         R x = o.x + (t2 * d.x);
         R z = o.z + (t2 * d.z);
         R lim = CONE ? Num<R>::abs_(ymax) : R(1);
-        if (x * x + z * z <= lim) emit(t2);
+        emit(t2, x * x + z * z <= lim);
     }
 }
 // the wall roots shared by cylinder and cone: cylinders.rs:37-60, cones.rs:54-78
@@ -281,9 +283,9 @@ RT_DEV bool isect_wall(R a, R b, R c, V3<R> o, V3<R> d, R ymin, R ymax, Emit &&e
     R t1 = Num<R>::div(-b + sq, two_a);
     if (t0 > t1) { R tmp = t0; t0 = t1; t1 = tmp; }
     R y0 = o.y + (t0 * d.y);
-    if (ymin < y0 && y0 < ymax) emit(t0);
+    emit(t0, ymin < y0 && y0 < ymax);
     R y1 = o.y + (t1 * d.y);
-    if (ymin < y1 && y1 < ymax) emit(t1);
+    emit(t1, ymin < y1 && y1 < ymax);
     return true;
 }
 // src/shapes/cylinders.rs:27-64; o2 = 2 * origin, c = origin.x^2 + origin.z^2 - 1
@@ -305,9 +307,9 @@ RT_DEV void isect_cylinder(V3<R> o, V3<R> o2, R c, V3<R> d, R ymin, R ymax, bool
         const R s = Num<R>::sqrt_(rem * inv_a);
         const R t0 = -ha - s, t1 = -ha + s;
         const R y0 = o.y + t0 * d.y;
-        if (ymin < y0 && y0 < ymax) emit(t0);
+        emit(t0, ymin < y0 && y0 < ymax);
         const R y1 = o.y + t1 * d.y;
-        if (ymin < y1 && y1 < ymax) emit(t1);
+        emit(t1, ymin < y1 && y1 < ymax);
         isect_caps<R, false>(o, d, ymin, ymax, closed, emit);
         return;
     }
@@ -337,9 +339,9 @@ RT_DEV void isect_cone(V3<R> o, V3<R> o2, R c, V3<R> d, R ymin, R ymax, bool clo
                 double t0 = (-b - sq) / (2.0 * a), t1 = (-b + sq) / (2.0 * a);
                 if (t0 > t1) { const double tmp = t0; t0 = t1; t1 = tmp; }
                 const double y0 = oy + t0 * dy;
-                if (ymin < y0 && y0 < ymax) emit(R(t0));
+                emit(R(t0), ymin < y0 && y0 < ymax);
                 const double y1 = oy + t1 * dy;
-                if (ymin < y1 && y1 < ymax) emit(R(t1));
+                emit(R(t1), ymin < y1 && y1 < ymax);
             }
         }
         isect_caps<R, true>(o, d, ymin, ymax, closed, emit);
@@ -439,18 +441,59 @@ static __device__ unsigned long long g_walk[8];
 #define RTX_WALK_COUNT(k) do {} while (0)
 #endif
 #define RT_CONSTANT_AS __attribute__((address_space(4)))
+// One value of a table that no kernel writes while it is read (object tables, and the queue
+// lengths the previous launch left): through the constant address space, so that a wave-uniform
+// address becomes a scalar load even after stores to other memory.
+template <typename T> RT_DEV T ro_load(const T *p) { return *(const RT_CONSTANT_AS T *)p; }
 template <typename Rec> RT_DEV Rec load_uniform(const Rec *p)
 {
     Rec rec;
     __builtin_memcpy(&rec, (const RT_CONSTANT_AS Rec *)p, sizeof(Rec));
     return rec;
 }
+#ifdef RTX_LDS_TABLES
+// Experiment (tools build): the five intersection tables are copied into LDS when a workgroup
+// starts (stage_tables) and the brute-force walk reads its records from there, every lane the
+// same address (a broadcast read into vector registers), instead of through the scalar cache
+// into scalar registers.  Only for scenes whose tables fit (no bounding-sphere walk).
+extern __shared__ __attribute__((aligned(16))) unsigned char rtx_lds_tab[];
+template <typename R> struct LdsOffsets { uint32_t sph, pln, cub, cyl, con, end; };
+template <typename R> RT_DEV LdsOffsets<R> lds_offsets(const SceneDev<R> &S)
+{
+    LdsOffsets<R> o;
+    o.sph = 0;
+    o.pln = o.sph + S.n_sph * (uint32_t)sizeof(XformRec<R>);
+    o.cub = o.pln + S.n_pln * (uint32_t)sizeof(PlaneRec<R>);
+    o.cyl = o.cub + S.n_cub * (uint32_t)sizeof(XformRec<R>);
+    o.con = o.cyl + S.n_cyl * (uint32_t)sizeof(CappedRec<R>);
+    o.end = o.con + S.n_con * (uint32_t)sizeof(CappedRec<R>);
+    return o;
+}
+template <typename R> RT_DEV void stage_tables(const SceneDev<R> &S)
+{
+    const LdsOffsets<R> o = lds_offsets(S);
+    const void *src[5] = { S.sph, S.pln, S.cub, S.cyl, S.con };
+    const uint32_t at[6] = { o.sph, o.pln, o.cub, o.cyl, o.con, o.end };
+    for (int t = 0; t < 5; ++t) {
+        const uint4 *from = (const uint4 *)src[t];
+        uint4 *to = (uint4 *)(rtx_lds_tab + at[t]);
+        for (uint32_t i = threadIdx.x; i < (at[t + 1] - at[t]) / 16u; i += blockDim.x) to[i] = from[i];
+    }
+    __syncthreads();
+}
+template <typename Rec> RT_DEV Rec load_lds(uint32_t byte_off, uint32_t i)
+{
+    Rec rec;
+    __builtin_memcpy(&rec, (const __attribute__((address_space(3))) Rec *)(rtx_lds_tab + byte_off) + i, sizeof(Rec));
+    return rec;
+}
+#endif
 // keep.object(slot) says whether this lane's ray can hit the object at all; the record is fetched
 // only when some lane's can.  With Keep::clustered the slots are visited group by group and
 // cluster by cluster, and keep.group(g) / keep.cluster(c) are asked first.
 template <typename Rec, typename Keep, typename Body>
 RT_DEV void walk_table(const Rec *recs, uint32_t n, uint32_t slot0, uint32_t cluster0, uint32_t group0, const Keep &keep,
-                       Body &&body)
+                       Body &&body, uint32_t lds_off = 0xffffffffu)
 {
     if constexpr (Keep::clustered) {
         // Spheres are fetched four at a time: a walk is a chain of scalar loads, each of which
@@ -489,7 +532,11 @@ RT_DEV void walk_table(const Rec *recs, uint32_t n, uint32_t slot0, uint32_t clu
         }
     } else {
         for (uint32_t i = 0; i < n; ++i) {
+#ifdef RTX_LDS_TABLES
+            const Rec rec = lds_off != 0xffffffffu ? load_lds<Rec>(lds_off, i) : load_uniform(recs + i);
+#else
             const Rec rec = load_uniform(recs + i);
+#endif
             body(rec, slot0 + i);
         }
     }
@@ -525,6 +572,55 @@ struct SphereCull {
     RT_DEV void cluster4(uint32_t c, bool outer, bool *out) const { four(cl + c, outer, out); }
     RT_DEV bool group(uint32_t g) const { return !(stop && *stop) && may_hit<R, LINE>(load_uniform(grp + g), cr, reach()); }
 };
+
+// Experiment (tools build, -DRTX_LANE_WALK; measured slower, see tools/README.md):
+// the same three-level walk with every lane on its own: for rays that have nothing to do with
+// each other (reflected and refracted rays, and the shadow rays of their hits) the wave-uniform
+// walk above visits the union of what 64 rays need, which is most of the scene, one dependent
+// scalar fetch after another.  Here each lane keeps its own position (next group, the clusters
+// of the group it is in, the objects of the cluster it is in), fetches the sphere its own
+// position names with a vector load, and steps; a lane that reaches an object whose sphere it
+// may hit waits for the others to get that far (or to run out), then the exact intersections run
+// together.  Same tests, same spheres, same result: only the order in which a ray meets the
+// objects changes, and ties between equal t are settled by World index, not by order.
+#ifdef RTX_LANE_WALK
+constexpr bool kLaneWalk = true;
+#else
+constexpr bool kLaneWalk = false;
+#endif
+template <typename R, bool LINE, typename Rec, typename Body>
+RT_DEV void lane_walk_table(const Rec *recs, uint32_t n, uint32_t slot0, uint32_t cluster0, uint32_t group0,
+                            const SphereCull<R, LINE> &keep, Body &&body)
+{
+    if (n == 0u) return;
+    const uint32_t n_cl = (n + kCluster - 1) / kCluster, n_grp = (n_cl + kCluster - 1) / kCluster;
+    uint32_t g = keep.cr.dead ? n_grp : 0u, c = 0u, c_end = 0u, i = 0u, i_end = 0u;
+    for (;;) {
+        bool found = false;
+        uint32_t at = 0u;
+        for (;;) {
+            const bool stopped = keep.stop && *keep.stop;
+            const uint32_t level = stopped ? 3u : i < i_end ? 0u : c < c_end ? 1u : g < n_grp ? 2u : 3u;
+            if (level == 3u) break;
+            const BoundRec<R> *p = level == 0u ? keep.bnd + slot0 + i : level == 1u ? keep.cl + cluster0 + c : keep.grp + group0 + g;
+            const BoundRec<R> b = *p;
+            const bool hit = may_hit<R, LINE>(b, keep.cr, keep.reach());
+            if (level == 0u) {
+                at = i++;
+                if (hit) { found = true; break; }
+            } else if (level == 1u) {
+                if (hit) { i = c * kCluster; i_end = i + kCluster < n ? i + kCluster : n; }
+                ++c;
+            } else {
+                if (hit) { c = g * kCluster; c_end = c + kCluster < n_cl ? c + kCluster : n_cl; }
+                ++g;
+            }
+        }
+        if (!found) break;
+        const Rec rec = recs[at];
+        body(rec, slot0 + at);
+    }
+}
 
 // Object::intersect for every object of the world (src/shapes/objects.rs:185-198 with
 // src/rays.rs:30-34): the ray goes into object space (direction not renormalised), then the
@@ -562,22 +658,66 @@ RT_DEV void walk_chained(const SceneDev<R> &S, V3<R> ro, V3<R> rd, Per &&per)
     }
 }
 
-template <typename R, bool CHAIN, typename Keep, typename Per>
+// `table(recs, n, slot0, cluster0, group0, body)`: one table, walked wave by wave or lane by lane
+template <typename R, bool CHAIN, bool LANE = false, typename Keep, typename Per>
 RT_DEV void walk_scene(const SceneDev<R> &S, V3<R> ro, V3<R> rd, const Keep &keep, Per &&per)
 {
+    if constexpr (LANE && Keep::clustered) {
+        uint32_t base = 0;
+        lane_walk_table(S.sph, S.n_sph, base, S.cl_off[SH_SPHERE], S.grp_off[SH_SPHERE], keep, [&](const XformRec<R> &rec, uint32_t slot) {
+            const V3<R> o = xform_point(rec.m, ro);
+            const V3<R> d = xform_vector(rec.m, rd);
+            per(slot, [&](auto &&emit) { isect_sphere(o, d, sphere_c(o), emit); });
+        });
+        base += S.n_sph;
+        walk_table(S.pln, S.n_pln, base, 0u, 0u, KeepAll(), [&](const PlaneRec<R> &rec, uint32_t slot) {
+            const R oy = ((rec.m[0] * ro.x + rec.m[1] * ro.y) + rec.m[2] * ro.z) + rec.m[3];
+            const R dy = (rec.m[0] * rd.x + rec.m[1] * rd.y) + rec.m[2] * rd.z;
+            per(slot, [&](auto &&emit) { isect_plane(-oy, dy, emit); });
+        });
+        base += S.n_pln;
+        lane_walk_table(S.cub, S.n_cub, base, S.cl_off[SH_CUBE], S.grp_off[SH_CUBE], keep, [&](const XformRec<R> &rec, uint32_t slot) {
+            const V3<R> o = xform_point(rec.m, ro);
+            const V3<R> d = xform_vector(rec.m, rd);
+            const V3<R> lo = { R(-1) - o.x, R(-1) - o.y, R(-1) - o.z };
+            const V3<R> hi = { R(1) - o.x, R(1) - o.y, R(1) - o.z };
+            per(slot, [&](auto &&emit) { isect_cube(lo, hi, d, emit); });
+        });
+        base += S.n_cub;
+        lane_walk_table(S.cyl, S.n_cyl, base, S.cl_off[SH_CYLINDER], S.grp_off[SH_CYLINDER], keep, [&](const CappedRec<R> &rec, uint32_t slot) {
+            const V3<R> o = xform_point(rec.m, ro);
+            const V3<R> d = xform_vector(rec.m, rd);
+            per(slot, [&](auto &&emit) { isect_cylinder(o, twice(o), cylinder_c(o), d, rec.ymin, rec.ymax, rec.closed != 0, emit); });
+        });
+        base += S.n_cyl;
+        walk_table(S.con, S.n_con, base, 0u, 0u, KeepAll(), [&](const CappedRec<R> &rec, uint32_t slot) {
+            const V3<R> o = xform_point(rec.m, ro);
+            const V3<R> d = xform_vector(rec.m, rd);
+            per(slot, [&](auto &&emit) { isect_cone(o, twice(o), cone_c(o), d, rec.ymin, rec.ymax, rec.closed != 0, emit); });
+        });
+        if constexpr (CHAIN) walk_chained(S, ro, rd, per);
+        return;
+    }
     uint32_t slot0 = 0;
+#ifdef RTX_LDS_TABLES
+    const LdsOffsets<R> lo_ = lds_offsets(S);
+    constexpr bool kLds = !Keep::clustered;
+#define RTX_LDS_ARG(f) , (kLds ? lo_.f : 0xffffffffu)
+#else
+#define RTX_LDS_ARG(f)
+#endif
     walk_table(S.sph, S.n_sph, slot0, S.cl_off[SH_SPHERE], S.grp_off[SH_SPHERE], keep, [&](const XformRec<R> &rec, uint32_t slot) {
         const V3<R> o = xform_point(rec.m, ro);
         const V3<R> d = xform_vector(rec.m, rd);
         per(slot, [&](auto &&emit) { isect_sphere(o, d, sphere_c(o), emit); });
-    });
+    } RTX_LDS_ARG(sph));
     slot0 += S.n_sph;
     walk_table(S.pln, S.n_pln, slot0, 0u, 0u, KeepAll(), [&](const PlaneRec<R> &rec, uint32_t slot) {
         // only the y row of the object-space ray is read by planes.rs:11-17
         const R oy = ((rec.m[0] * ro.x + rec.m[1] * ro.y) + rec.m[2] * ro.z) + rec.m[3];
         const R dy = (rec.m[0] * rd.x + rec.m[1] * rd.y) + rec.m[2] * rd.z;
         per(slot, [&](auto &&emit) { isect_plane(-oy, dy, emit); });
-    });
+    } RTX_LDS_ARG(pln));
     slot0 += S.n_pln;
     walk_table(S.cub, S.n_cub, slot0, S.cl_off[SH_CUBE], S.grp_off[SH_CUBE], keep, [&](const XformRec<R> &rec, uint32_t slot) {
         const V3<R> o = xform_point(rec.m, ro);
@@ -585,19 +725,20 @@ RT_DEV void walk_scene(const SceneDev<R> &S, V3<R> ro, V3<R> rd, const Keep &kee
         const V3<R> lo = { R(-1) - o.x, R(-1) - o.y, R(-1) - o.z };
         const V3<R> hi = { R(1) - o.x, R(1) - o.y, R(1) - o.z };
         per(slot, [&](auto &&emit) { isect_cube(lo, hi, d, emit); });
-    });
+    } RTX_LDS_ARG(cub));
     slot0 += S.n_cub;
     walk_table(S.cyl, S.n_cyl, slot0, S.cl_off[SH_CYLINDER], S.grp_off[SH_CYLINDER], keep, [&](const CappedRec<R> &rec, uint32_t slot) {
         const V3<R> o = xform_point(rec.m, ro);
         const V3<R> d = xform_vector(rec.m, rd);
         per(slot, [&](auto &&emit) { isect_cylinder(o, twice(o), cylinder_c(o), d, rec.ymin, rec.ymax, rec.closed != 0, emit); });
-    });
+    } RTX_LDS_ARG(cyl));
     slot0 += S.n_cyl;
     walk_table(S.con, S.n_con, slot0, 0u, 0u, KeepAll(), [&](const CappedRec<R> &rec, uint32_t slot) {
         const V3<R> o = xform_point(rec.m, ro);
         const V3<R> d = xform_vector(rec.m, rd);
         per(slot, [&](auto &&emit) { isect_cone(o, twice(o), cone_c(o), d, rec.ymin, rec.ymax, rec.closed != 0, emit); });
-    });
+    } RTX_LDS_ARG(con));
+#undef RTX_LDS_ARG
     if constexpr (CHAIN) walk_chained(S, ro, rd, per);
 }
 
@@ -740,11 +881,11 @@ RT_DEV Hit<R> closest_hit_with(const SceneDev<R> &S, Walk &&walk)
     h.top1 = h.top2 = kNone;
     h.top1_t = h.top2_t = -Num<R>::inf;
     // true when `slot` precedes `other` in World.objects
-    auto before = [&](uint32_t slot, uint32_t other) { return S.slot_obj[slot] < S.slot_obj[other]; };
+    auto before = [&](uint32_t slot, uint32_t other) { return ro_load(S.slot_obj + slot) < ro_load(S.slot_obj + other); };
     walk(&h.t, [&](uint32_t slot, auto &&run) {
         if constexpr (!TRACK) {
-            run([&](R t) {
-                if (t >= R(0) && t <= h.t) {
+            run([&](R t, bool ok = true) {
+                if (ok && t >= R(0) && t <= h.t) {
                     if (t < h.t || h.slot == kNone || (h.slot != slot && before(slot, h.slot))) { h.t = t; h.slot = slot; }
                 }
             });
@@ -753,12 +894,15 @@ RT_DEV Hit<R> closest_hit_with(const SceneDev<R> &S, Walk &&walk)
             R last_neg = -Num<R>::inf;  // largest t < 0 of this object
             uint32_t n_neg = 0;
             bool any_pos = false;
-            run([&](R t) {
-                if (t >= R(0)) { best = Num<R>::min_(best, t); any_pos = true; }
-                else if (t < R(0)) { n_neg++; last_neg = Num<R>::max_(last_neg, t); }
+            run([&](R t, bool ok = true) {
+                const bool pos = ok && t >= R(0), neg = ok && t < R(0);
+                best = Num<R>::min_(best, pos ? t : Num<R>::inf);
+                any_pos = any_pos || pos;
+                n_neg += neg ? 1u : 0u;
+                last_neg = Num<R>::max_(last_neg, neg ? t : -Num<R>::inf);
             });
             bool open = false;
-            if (n_neg & 1u) open = (S.cold[S.slot_obj[slot]].flags & OF_CONTAINER) != 0;
+            if (n_neg & 1u) open = (ro_load(&S.cold[ro_load(S.slot_obj + slot)].flags) & OF_CONTAINER) != 0;
             if (any_pos && best <= h.t) {
                 if (best < h.t || h.slot == kNone || before(slot, h.slot)) { h.t = best; h.slot = slot; h.hit_open = open; }
             }
@@ -775,18 +919,18 @@ RT_DEV Hit<R> closest_hit_with(const SceneDev<R> &S, Walk &&walk)
             }
         }
     });
-    if (h.slot != kNone) h.obj = S.slot_obj[h.slot];
+    if (h.slot != kNone) h.obj = ro_load(S.slot_obj + h.slot);
     return h;
 }
 // The closest-hit walks.  t_limit: hits beyond it need not be found (inf for color_at; the
 // distance to the light for a shadow ray, which only asks whether the closest hit lies before it).
-template <typename R, bool TRACK, bool CULL, bool CHAIN>
+template <typename R, bool TRACK, bool CULL, bool CHAIN, bool LANE = false>
 RT_DEV Hit<R> closest_hit(const SceneDev<R> &S, V3<R> ro, V3<R> rd, R t_limit)
 {
     if constexpr (CULL) {
         return closest_hit_with<R, TRACK>(S, [&](const R *best, auto &&per) {
             const SphereCull<R, TRACK> keep = { S.bnd, S.cl, S.grp, cull_ray(ro, rd), best, t_limit, nullptr };
-            walk_scene<R, CHAIN>(S, ro, rd, keep, per);
+            walk_scene<R, CHAIN, LANE>(S, ro, rd, keep, per);
         });
     } else {
         return closest_hit_with<R, TRACK>(S, [&](const R *, auto &&per) { walk_scene<R, CHAIN>(S, ro, rd, KeepAll(), per); });
@@ -808,7 +952,7 @@ RT_DEV Hit<R> closest_hit_primary(const SceneDev<R> &S, const PrimScene<R> &P, V
 // src/scenes/world.rs:146-158.  shadowed iff the closest hit (t >= 0) lies before the light
 // and its object casts a shadow.  When every object casts, any hit with 0 <= t < distance
 // decides it, so the walk needs no closest-hit bookkeeping.
-template <typename R, uint32_t SF>
+template <typename R, uint32_t SF, bool LANE = false>
 RT_DEV bool is_shadowed(const SceneDev<R> &S, V3<R> p, V3<R> dir, R distance)
 {
     constexpr bool CULL = (SF & SF_CULL) != 0;
@@ -816,19 +960,19 @@ RT_DEV bool is_shadowed(const SceneDev<R> &S, V3<R> p, V3<R> dir, R distance)
     if constexpr ((SF & SF_ALL_CAST) != 0) {
         bool shadowed = false;
         auto per = [&](uint32_t, auto &&run) {
-            run([&](R t) {
-                if (t >= R(0) && t < distance) shadowed = true;
+            run([&](R t, bool ok = true) {
+                if (ok && t >= R(0) && t < distance) shadowed = true;
             });
         };
         if constexpr (CULL) {
             const SphereCull<R, false> keep = { S.bnd, S.cl, S.grp, cull_ray(p, dir), nullptr, distance, &shadowed };
-            walk_scene<R, CHAIN>(S, p, dir, keep, per);
+            walk_scene<R, CHAIN, LANE>(S, p, dir, keep, per);
         } else {
             walk_scene<R, CHAIN>(S, p, dir, KeepAll(), per);
         }
         return shadowed;
     } else {
-        Hit<R> h = closest_hit<R, false, CULL, CHAIN>(S, p, dir, distance);
+        Hit<R> h = closest_hit<R, false, CULL, CHAIN, LANE>(S, p, dir, distance);
         if (h.slot == kNone) return false;
         return h.t < distance && (S.cold[h.obj].flags & OF_CASTS_SHADOW) != 0;
     }
@@ -910,8 +1054,37 @@ struct Node {
     R refract_factor;     // transparency [* (1 - schlick)]
 };
 
-template <typename R, uint32_t SF, bool PRIMARY = false>
-RT_DEV Node<R> trace_node(const SceneDev<R> &S, const PrimScene<R> *P, V3<R> ro, V3<R> rd, uint32_t remaining)
+#ifdef RTX_PHASE_CLOCK
+// Diagnostic build: cycles per phase of a color_at node, summed over waves (tools/phase_clock.py)
+static __device__ unsigned long long g_phase[16];
+// per-wave sums in LDS; a kernel clears them when it starts and adds them to g_phase when it ends
+__device__ __forceinline__ unsigned long long *phase_lds()
+{
+    __shared__ unsigned long long acc[4][16];
+    return acc[threadIdx.x >> 6];
+}
+__device__ __forceinline__ bool phase_leader() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == (uint32_t)(__ffsll((long long)__ballot(1)) - 1); }
+#define RTX_PHASE_MARK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (phase_leader()) phase_lds()[k] += now_ - phase_t_; phase_t_ = __builtin_readcyclecounter(); } while (0)
+#define RTX_PHASE_BEGIN() unsigned long long phase_t_ = __builtin_readcyclecounter()
+#define RTX_PHASE_INIT() do { if ((threadIdx.x & 63u) < 16u) phase_lds()[threadIdx.x & 63u] = 0ull; } while (0)
+#define RTX_PHASE_FLUSH() do { if ((threadIdx.x & 63u) < 16u && phase_lds()[threadIdx.x & 63u]) atomicAdd(&g_phase[threadIdx.x & 63u], phase_lds()[threadIdx.x & 63u]); } while (0)
+#else
+#define RTX_PHASE_MARK(k) do {} while (0)
+#define RTX_PHASE_BEGIN() do {} while (0)
+#define RTX_PHASE_INIT() do {} while (0)
+#define RTX_PHASE_FLUSH() do {} while (0)
+#endif
+// `children(nd)` is called for every ray that hits something, as soon as its child rays are
+// known and before the shadow ray and the lighting are evaluated: a kernel that queues the
+// children there has their registers free during the second walk.  The call sits in divergent
+// control flow (the lanes whose ray missed are not there): wave-level operations inside it see
+// the lanes that hit.
+struct NoChildrenHook {
+    template <typename N> RT_DEV void operator()(const N &) const {}
+};
+template <typename R, uint32_t SF, bool PRIMARY = false, bool LANE = false, typename Children = NoChildrenHook>
+RT_DEV Node<R> trace_node(const SceneDev<R> &S, const PrimScene<R> *P, V3<R> ro, V3<R> rd, uint32_t remaining,
+                          Children &&children = Children())
 {
     constexpr bool TRACK = (SF & SF_TRANSPARENT) != 0;
     Node<R> nd;
@@ -920,8 +1093,10 @@ RT_DEV Node<R> trace_node(const SceneDev<R> &S, const PrimScene<R> *P, V3<R> ro,
     Hit<R> h;
     constexpr bool CULL = (SF & SF_CULL) != 0;
     constexpr bool CHAIN = (SF & SF_CHAIN) != 0;
+    RTX_PHASE_BEGIN();
     if constexpr (PRIMARY) h = closest_hit_primary<R, TRACK, CULL, CHAIN>(S, *P, ro, rd);
-    else h = closest_hit<R, TRACK, CULL, CHAIN>(S, ro, rd, Num<R>::inf);
+    else h = closest_hit<R, TRACK, CULL, CHAIN, LANE>(S, ro, rd, Num<R>::inf);
+    RTX_PHASE_MARK(PRIMARY ? 8 : 0);
     nd.hit = h.slot != kNone;
     nd.obj = h.obj;
     nd.t = h.t;
@@ -971,46 +1146,6 @@ RT_DEV Node<R> trace_node(const SceneDev<R> &S, const PrimScene<R> *P, V3<R> ro,
 
     nd.point = pt; nd.normalv = normalv; nd.over_point = over; nd.under_point = under; nd.reflectv = reflectv;
     nd.inside = inside; nd.n1 = n1; nd.n2 = n2;
-
-    // shade_hit, world.rs:121-123.  is_shadowed (world.rs:146-150) and lighting (lights.rs:49)
-    // both normalise light.position - over_point; the vector is formed once here.
-    V3<R> lvec = { S.light_pos[0] - over.x, S.light_pos[1] - over.y, S.light_pos[2] - over.z };
-    R ldist;
-    V3<R> lightv = normalized(lvec, (lvec.x * lvec.x + lvec.y * lvec.y) + lvec.z * lvec.z, &ldist);
-    bool shadowed = is_shadowed<R, SF>(S, over, lightv, ldist);
-    nd.shadowed = shadowed;
-
-    // lighting, lights.rs:43-78, evaluated at over_point
-    V3<R> clr = { cold.color[0], cold.color[1], cold.color[2] };
-    if constexpr ((SF & SF_PATTERN) != 0) {
-        if (cold.pattern_type != PT_SOLID) {  // Object::pattern_at_object, objects.rs:200-207
-            V3<R> op = xform_point(cold.inv, over);
-            V3<R> pp = xform_point(cold.pinv, op);
-            clr = pattern_at<R>(cold.pattern_type, { cold.c1[0], cold.c1[1], cold.c1[2] },
-                                { cold.c2[0], cold.c2[1], cold.c2[2] }, pp);
-        }
-    }
-    V3<R> li = { S.light_int[0], S.light_int[1], S.light_int[2] };
-    V3<R> eff = { clr.x * li.x, clr.y * li.y, clr.z * li.z };
-    V3<R> result = { eff.x * cold.ambient, eff.y * cold.ambient, eff.z * cold.ambient };
-    if (!shadowed) {
-        V3<R> diffuse = { R(0), R(0), R(0) }, specular = { R(0), R(0), R(0) };
-        R ldn = dot3(lightv, normalv);
-        if (ldn >= R(0)) {
-            diffuse = { (eff.x * cold.diffuse) * ldn, (eff.y * cold.diffuse) * ldn, (eff.z * cold.diffuse) * ldn };
-            R l2 = R(2) * dot3(lightv, normalv);
-            V3<R> rv = { -(lightv.x - normalv.x * l2), -(lightv.y - normalv.y * l2), -(lightv.z - normalv.z * l2) };
-            R rde = dot3(rv, eyev);
-            if (!(rde <= R(0))) {
-                R factor = Num<R>::pow_(rde, cold.shininess);
-                specular = { (li.x * cold.specular) * factor, (li.y * cold.specular) * factor,
-                             (li.z * cold.specular) * factor };
-            }
-        }
-        result = { (result.x + diffuse.x) + specular.x, (result.y + diffuse.y) + specular.y,
-                   (result.z + diffuse.z) + specular.z };
-    }
-    nd.lighting = result;
 
     // reflected_color, world.rs:160-173
     R reflective = R(0), transparency = R(0);
@@ -1064,6 +1199,52 @@ RT_DEV Node<R> trace_node(const SceneDev<R> &S, const PrimScene<R> *P, V3<R> ro,
             nd.refract_factor = transparency * (R(1) - reflectance);
         }
     }
+    RTX_PHASE_MARK(PRIMARY ? 9 : 1);
+    children(nd);
+    RTX_PHASE_MARK(PRIMARY ? 10 : 2);
+
+    // shade_hit, world.rs:121-123.  is_shadowed (world.rs:146-150) and lighting (lights.rs:49)
+    // both normalise light.position - over_point; the vector is formed once here.
+    V3<R> lvec = { S.light_pos[0] - over.x, S.light_pos[1] - over.y, S.light_pos[2] - over.z };
+    R ldist;
+    V3<R> lightv = normalized(lvec, (lvec.x * lvec.x + lvec.y * lvec.y) + lvec.z * lvec.z, &ldist);
+    bool shadowed = is_shadowed<R, SF, LANE>(S, over, lightv, ldist);
+    nd.shadowed = shadowed;
+    RTX_PHASE_MARK(PRIMARY ? 11 : 3);
+
+    // lighting, lights.rs:43-78, evaluated at over_point
+    V3<R> clr = { cold.color[0], cold.color[1], cold.color[2] };
+    if constexpr ((SF & SF_PATTERN) != 0) {
+        if (cold.pattern_type != PT_SOLID) {  // Object::pattern_at_object, objects.rs:200-207
+            V3<R> op = xform_point(cold.inv, over);
+            V3<R> pp = xform_point(cold.pinv, op);
+            clr = pattern_at<R>(cold.pattern_type, { cold.c1[0], cold.c1[1], cold.c1[2] },
+                                { cold.c2[0], cold.c2[1], cold.c2[2] }, pp);
+        }
+    }
+    V3<R> li = { S.light_int[0], S.light_int[1], S.light_int[2] };
+    V3<R> eff = { clr.x * li.x, clr.y * li.y, clr.z * li.z };
+    V3<R> result = { eff.x * cold.ambient, eff.y * cold.ambient, eff.z * cold.ambient };
+    if (!shadowed) {
+        V3<R> diffuse = { R(0), R(0), R(0) }, specular = { R(0), R(0), R(0) };
+        R ldn = dot3(lightv, normalv);
+        if (ldn >= R(0)) {
+            diffuse = { (eff.x * cold.diffuse) * ldn, (eff.y * cold.diffuse) * ldn, (eff.z * cold.diffuse) * ldn };
+            R l2 = R(2) * dot3(lightv, normalv);
+            V3<R> rv = { -(lightv.x - normalv.x * l2), -(lightv.y - normalv.y * l2), -(lightv.z - normalv.z * l2) };
+            R rde = dot3(rv, eyev);
+            if (!(rde <= R(0))) {
+                R factor = Num<R>::pow_(rde, cold.shininess);
+                specular = { (li.x * cold.specular) * factor, (li.y * cold.specular) * factor,
+                             (li.z * cold.specular) * factor };
+            }
+        }
+        result = { (result.x + diffuse.x) + specular.x, (result.y + diffuse.y) + specular.y,
+                   (result.z + diffuse.z) + specular.z };
+    }
+    nd.lighting = result;
+    RTX_PHASE_MARK(PRIMARY ? 12 : 4);
+
     return nd;
 }
 

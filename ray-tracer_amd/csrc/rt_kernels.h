@@ -28,39 +28,53 @@ template <typename R> RT_DEV R pixel_bits_store(uint32_t p);
 template <> RT_DEV double pixel_bits_store<double>(uint32_t p) { return __longlong_as_double((long long)p); }
 template <> RT_DEV float pixel_bits_store<float>(uint32_t p) { return __uint_as_float(p); }
 
-// Append (o, d, weight, pixel) to sub-queue `sub` for every lane with `active` set.  Must be
-// reached by all lanes of the wave (inactive ones pass active = false): the wave reserves its
-// slots with one atomic.
-template <typename R>
-RT_DEV void queue_push(const QueueDev<R> &q, uint32_t sub, bool active, V3<R> o, V3<R> d, R weight, uint32_t pixel,
-                       StatShard *__restrict__ stats)
+// 16 bytes of a queue entry: the unit the entries travel in between memory, LDS and registers.
+// A queue is laid out in planes: chunk j of entry idx of sub-queue q sits at chunk index
+// (j * n_sub + q) * cap_sub + idx, so that the consecutive entries a wave appends or consumes
+// are consecutive in memory for every one of its store and load instructions (one instruction
+// moves 64 x 16 contiguous bytes; entry by entry it would touch 64 separate cache lines, and the
+// address unit of the CU, which takes a line per cycle, becomes what the kernel waits for).
+struct alignas(16) QueueChunk {
+    uint32_t w[4];
+};
+template <typename R> constexpr uint32_t kEntryChunks = 8 * sizeof(R) / 16;
+template <typename R> RT_DEV size_t chunk_index(const QueueDev<R> &q, uint32_t j, uint32_t sub, uint32_t idx)
 {
-    const unsigned long long mask = __ballot(active);
-    if (mask == 0ull) return;
-    const uint32_t lane = lane_id();
-    const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(q.count + (size_t)sub * kCountStride, (uint32_t)__popcll(mask));
-    base = __shfl(base, (int)leader);
-    if (active) {
-        const uint32_t idx = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        if (idx < q.cap_sub) {
-            using V2 = typename Vec2T<R>::type;
-            V2 *dst = reinterpret_cast<V2 *>(q.rec) + ((size_t)sub * q.cap_sub + idx) * 4;
-            V2 a, b, c, e;
-#ifdef RTX_EXPERIMENT_ROUND_RAYS
-            o = { R(float(o.x)), R(float(o.y)), R(float(o.z)) };
-            d = { R(float(d.x)), R(float(d.y)), R(float(d.z)) };
-#endif
-            a.x = o.x; a.y = o.y;
-            b.x = o.z; b.y = d.x;
-            c.x = d.y; c.y = d.z;
-            e.x = weight; e.y = pixel_bits_store<R>(pixel);
-            dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = e;
-        } else {
-            atomicAdd(&stats->overflow, 1ull);  // cannot happen: queues are sized for the worst case
-        }
+    return ((size_t)j * (q.sub_mask + 1u) + sub) * q.cap_sub + idx;
+}
+template <typename R>
+RT_DEV void queue_store(const QueueDev<R> &q, uint32_t sub, uint32_t idx, V3<R> o, V3<R> d, R weight, uint32_t pixel,
+                        StatShard *__restrict__ stats)
+{
+    if (idx < q.cap_sub) {
+        const R v[8] = { o.x, o.y, o.z, d.x, d.y, d.z, weight, pixel_bits_store<R>(pixel) };
+        QueueChunk c[kEntryChunks<R>];
+        __builtin_memcpy(c, v, sizeof v);
+        QueueChunk *dst = reinterpret_cast<QueueChunk *>(q.rec);
+        for (uint32_t j = 0; j < kEntryChunks<R>; ++j) dst[chunk_index(q, j, sub, idx)] = c[j];
+    } else {
+        atomicAdd(&stats->overflow, 1ull);  // cannot happen: queues are sized for the worst case
     }
+}
+// Append the children of one color_at node to sub-queue `sub` of the next level: the reflection
+// ray (o1, d1, w1) where has1, the refraction ray (o2, d2, w2) where has2.  The lanes that call
+// this together reserve all their slots with ONE atomic (issued by the first of them), the
+// reflection rays first, then the refraction rays.
+template <typename R>
+RT_DEV void queue_push2(const QueueDev<R> &q, uint32_t sub, bool has1, V3<R> o1, V3<R> d1, R w1, bool has2, V3<R> o2, V3<R> d2,
+                        R w2, uint32_t pixel, StatShard *__restrict__ stats)
+{
+    const unsigned long long m1 = __ballot(has1), m2 = __ballot(has2);
+    if ((m1 | m2) == 0ull) return;
+    const uint32_t lane = lane_id();
+    const uint32_t leader = (uint32_t)__ffsll((long long)(m1 | m2)) - 1u;
+    const uint32_t n1 = (uint32_t)__popcll(m1);
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(q.count + (size_t)sub * kCountStride, n1 + (uint32_t)__popcll(m2));
+    base = __shfl(base, (int)leader);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (has1) queue_store(q, sub, base + (uint32_t)__popcll(m1 & below), o1, d1, w1, pixel, stats);
+    if (has2) queue_store(q, sub, base + n1 + (uint32_t)__popcll(m2 & below), o2, d2, w2, pixel, stats);
 }
 
 // Count the shaded hits of this wave: one atomic per wave that has any, spread over shards.
@@ -85,19 +99,19 @@ RT_DEV void primary_ray(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> ro, V
     nd.hit = false;
     nd.has_reflect = nd.has_refract = false;
     nd.lighting = { R(0), R(0), R(0) };
+    const uint32_t sub = blockIdx.x & out_q.sub_mask;
     if (valid) {
-        nd = trace_node<R, SF, CAM>(S, CAM ? &P : nullptr, ro, rd, remaining);
+        nd = trace_node<R, SF, CAM, false>(S, CAM ? &P : nullptr, ro, rd, remaining, [&](const Node<R> &c) {
+            if constexpr ((SF & (SF_REFLECTIVE | SF_TRANSPARENT)) != 0)
+                queue_push2(out_q, sub, c.has_reflect, c.over_point, c.reflectv, c.reflect_factor, c.has_refract, c.under_point,
+                            c.refract_dir, c.refract_factor, k, stats);
+        });
         R *px = fb + (size_t)k * 3;
         px[0] = nd.lighting.x;
         px[1] = nd.lighting.y;
         px[2] = nd.lighting.z;
     }
     count_hits(stats, blockIdx.x, 0, valid && nd.hit);
-    const uint32_t sub = blockIdx.x & out_q.sub_mask;
-    if constexpr ((SF & SF_REFLECTIVE) != 0)
-        queue_push(out_q, sub, valid && nd.has_reflect, nd.over_point, nd.reflectv, nd.reflect_factor, k, stats);
-    if constexpr ((SF & SF_TRANSPARENT) != 0)
-        queue_push(out_q, sub, valid && nd.has_refract, nd.under_point, nd.refract_dir, nd.refract_factor, k, stats);
 }
 
 // Camera rays of rows [row0, row0 + n_rows), one pixel per lane.  Each wave takes one 64-pixel
@@ -113,6 +127,9 @@ __global__ void __launch_bounds__(kCamBlock) RTX_CAMERA_ATTR
 k_primary_camera(CameraDev<R> cam, SceneDev<R> S, PrimScene<R> P, uint32_t row0, uint32_t n_rows, uint32_t pieces_per_row,
                  uint32_t remaining, R *__restrict__ fb, QueueDev<R> out_q, StatShard *__restrict__ stats)
 {
+#ifdef RTX_LDS_TABLES
+    if constexpr ((SF & SF_CULL) == 0) stage_tables<R>(S);
+#endif
     const uint32_t piece = __builtin_amdgcn_readfirstlane(blockIdx.x * (kCamBlock / 64) + (threadIdx.x >> 6));
     const uint32_t piece_row = piece / pieces_per_row;
     const uint32_t piece_col = piece - piece_row * pieces_per_row;
@@ -126,8 +143,10 @@ k_primary_camera(CameraDev<R> cam, SceneDev<R> S, PrimScene<R> P, uint32_t row0,
     }
     const bool valid = row < n_rows && x < cam.hsize;
     V3<R> ro = { R(0), R(0), R(0) }, rd = ro;
+    RTX_PHASE_INIT();
     if (valid) ray_for_pixel(cam, x, row0 + row, ro, rd);
     primary_ray<R, SF, true>(S, P, ro, rd, row * cam.hsize + x, valid, remaining, fb, out_q, stats);
+    RTX_PHASE_FLUSH();
 }
 
 // Rays from a caller-supplied array (World::color_at batches), one per thread.
@@ -136,6 +155,9 @@ __global__ void __launch_bounds__(kRayBlock<R>)
 k_primary_rays(SceneDev<R> S, const double *__restrict__ rays, uint32_t n, uint32_t remaining, R *__restrict__ fb,
                QueueDev<R> out_q, StatShard *__restrict__ stats)
 {
+#ifdef RTX_LDS_TABLES
+    if constexpr ((SF & SF_CULL) == 0) stage_tables<R>(S);
+#endif
     const PrimScene<R> none = {};
     const uint32_t k = blockIdx.x * kRayBlock<R> + threadIdx.x;
     const bool valid = k < n;
@@ -159,67 +181,6 @@ k_frame_begin(CameraDev<R> cam, SceneDev<R> S, PrimScene<R> P, uint32_t n_tables
     if (i < n_a) zero_a[i] = 0u;
     if (i < n_b) zero_b[i] = 0u;
     if (i < n_tables) make_primary_record<R>(S, P, { cam.origin[0], cam.origin[1], cam.origin[2] }, i);
-}
-
-template <typename R> RT_DEV void fb_add(R *p, R v);
-template <> RT_DEV void fb_add<double>(double *p, double v) { unsafeAtomicAdd(p, v); }
-template <> RT_DEV void fb_add<float>(float *p, float v) { unsafeAtomicAdd(p, v); }
-
-// One recursion level: one queued ray per thread.  blockIdx.y selects the sub-queue and the
-// grid's x extent covers its worst-case length, so workgroups past the actual length leave at
-// once.  The children go to sub-queue (x + y) mod n_sub: every output sub-queue is fed by
-// exactly gridDim.x workgroups, which is the bound the host sizes cap_sub with.
-template <typename R, uint32_t SF>
-__global__ void __launch_bounds__(kRayBlock<R>)
-k_bounce(SceneDev<R> S, QueueDev<R> in_q, QueueDev<R> out_q, uint32_t remaining, uint32_t level,
-         R *__restrict__ fb, StatShard *__restrict__ stats)
-{
-    const uint32_t sub_in = blockIdx.y;
-    uint32_t n = in_q.count[(size_t)sub_in * kCountStride];
-    if (n > in_q.cap_sub) n = in_q.cap_sub;
-    // With bounding-sphere tests a wave walks the union of the spheres its rays can hit, one
-    // dependent fetch after another, and deep levels hold few, incoherent rays: their waves are
-    // long chains on a mostly idle chip.  While a level is short enough that the whole chip has
-    // lanes to spare, give every ray `spread` lanes' worth of room (one ray per `spread` lanes):
-    // more, shorter walks side by side.  The grid covers the worst-case length, so the room is
-    // there; the decision is uniform over the launch's y slice.
-    uint32_t spread = 1u;
-    if constexpr ((SF & SF_CULL) != 0) {
-        const uint32_t budget = kSpreadLanes / gridDim.y;  // lanes per sub-queue when the chip is lightly loaded
-        while (spread < 64u && (uint64_t)n * (spread * 2u) <= budget && (uint64_t)n * (spread * 2u) <= (uint64_t)gridDim.x * kRayBlock<R>)
-            spread *= 2u;
-    }
-    if ((uint64_t)blockIdx.x * kRayBlock<R> >= (uint64_t)n * spread) return;
-    const uint32_t lane_slot = blockIdx.x * kRayBlock<R> + threadIdx.x;
-    const uint32_t k = lane_slot / spread;
-    const bool valid = k < n && (lane_slot & (spread - 1u)) == 0u;
-    Node<R> nd;
-    nd.hit = false;
-    nd.has_reflect = nd.has_refract = false;
-    R weight = R(0);
-    uint32_t pixel = 0;
-    if (valid) {
-        using V2 = typename Vec2T<R>::type;
-        const V2 *src = reinterpret_cast<const V2 *>(in_q.rec) + ((size_t)sub_in * in_q.cap_sub + k) * 4;
-        const V2 a = src[0], b = src[1], c = src[2], e = src[3];
-        V3<R> ro = { a.x, a.y, b.x };
-        V3<R> rd = { b.y, c.x, c.y };
-        weight = e.x;
-        pixel = pixel_bits_load<R>(e.y);
-        nd = trace_node<R, SF, false>(S, nullptr, ro, rd, remaining);
-        if (nd.hit) {
-            R *px = fb + (size_t)pixel * 3;
-            fb_add<R>(px + 0, nd.lighting.x * weight);
-            fb_add<R>(px + 1, nd.lighting.y * weight);
-            fb_add<R>(px + 2, nd.lighting.z * weight);
-        }
-    }
-    count_hits(stats, blockIdx.x + blockIdx.y, level, valid && nd.hit);
-    const uint32_t sub = (blockIdx.x + blockIdx.y) & out_q.sub_mask;
-    if constexpr ((SF & SF_REFLECTIVE) != 0)
-        queue_push(out_q, sub, valid && nd.has_reflect, nd.over_point, nd.reflectv, weight * nd.reflect_factor, pixel, stats);
-    if constexpr ((SF & SF_TRANSPARENT) != 0)
-        queue_push(out_q, sub, valid && nd.has_refract, nd.under_point, nd.refract_dir, weight * nd.refract_factor, pixel, stats);
 }
 
 template <typename R>
@@ -298,6 +259,10 @@ constexpr uint32_t sf_case(uint32_t sf)
 {
     return (sf & SF_CHAIN) ? (16u | ((sf & SF_CULL) ? 1u : 0u)) : ((sf & 7u) | ((sf & SF_CULL) ? 8u : 0u));
 }
+#ifdef RTX_ONLY_SF
+// tools builds (ISA inspection, experiments): a single kernel variant, whatever the scene asks for
+#define RTX_SF_SWITCH(sf, CALL) { CALL((RTX_ONLY_SF)); }
+#else
 #define RTX_SF_SWITCH(sf, CALL)                                                \
     switch (sf_case(sf)) {                                                     \
     case 0u: CALL(sf_variant(0u)); break;                                      \
@@ -319,7 +284,19 @@ constexpr uint32_t sf_case(uint32_t sf)
     case 16u: CALL(sf_variant(16u)); break;                                    \
     default: CALL(sf_variant(17u)); break;                                     \
     }
+#endif
 
+// dynamic LDS a kernel is launched with: the intersection tables in the LDS-table experiment
+template <typename R> inline uint32_t table_lds_bytes(const SceneDev<R> &S)
+{
+#ifdef RTX_LDS_TABLES
+    if (S.flags & SF_CULL) return 0u;
+    return (uint32_t)((S.n_sph + S.n_cub) * sizeof(XformRec<R>) + S.n_pln * sizeof(PlaneRec<R>) + (S.n_cyl + S.n_con) * sizeof(CappedRec<R>) + 16u);
+#else
+    (void)S;
+    return 0u;
+#endif
+}
 template <typename R>
 hipError_t Launch<R>::primary_camera(uint32_t sf, hipStream_t stream, const CameraDev<R> &cam, const SceneDev<R> &scene,
                                      const PrimScene<R> &prim, uint32_t row0, uint32_t n_rows, uint32_t remaining, R *fb,
@@ -328,7 +305,7 @@ hipError_t Launch<R>::primary_camera(uint32_t sf, hipStream_t stream, const Came
     const uint32_t pieces_per_row = camera_pieces_per_row(sf, cam.hsize);
     const uint32_t grid = (uint32_t)camera_blocks(sf, cam.hsize, n_rows);
 #define RTX_CALL(SFV)                                                                                               \
-    hipLaunchKernelGGL((k_primary_camera<R, SFV | SF_PATTERN>), dim3(grid), dim3(kCamBlock), 0, stream, cam, scene, prim, \
+    hipLaunchKernelGGL((k_primary_camera<R, SFV | SF_PATTERN>), dim3(grid), dim3(kCamBlock), table_lds_bytes(scene), stream, cam, scene, prim, \
                        row0, n_rows, pieces_per_row, remaining, fb, out_q, stats)
     RTX_SF_SWITCH(sf, RTX_CALL)
 #undef RTX_CALL
@@ -341,7 +318,7 @@ hipError_t Launch<R>::primary_rays(uint32_t sf, hipStream_t stream, const SceneD
 {
     const uint32_t grid = (n + kRayBlock<R> - 1) / kRayBlock<R>;
 #define RTX_CALL(SFV)                                                                                           \
-    hipLaunchKernelGGL((k_primary_rays<R, SFV | SF_PATTERN>), dim3(grid), dim3(kRayBlock<R>), 0, stream, scene, rays, n, \
+    hipLaunchKernelGGL((k_primary_rays<R, SFV | SF_PATTERN>), dim3(grid), dim3(kRayBlock<R>), table_lds_bytes(scene), stream, scene, rays, n, \
                        remaining, fb, out_q, stats)
     RTX_SF_SWITCH(sf, RTX_CALL)
 #undef RTX_CALL
@@ -359,21 +336,6 @@ hipError_t Launch<R>::frame_begin(hipStream_t stream, const CameraDev<R> *cam, c
     if (cam) c = *cam;
     hipLaunchKernelGGL((k_frame_begin<R>), dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, c, scene, prim,
                        n_tables, zero_a, n_a, zero_b, n_b);
-    return hipGetLastError();
-}
-
-template <typename R>
-hipError_t Launch<R>::bounce(uint32_t sf, hipStream_t stream, const SceneDev<R> &scene, const QueueDev<R> &in_q,
-                             const QueueDev<R> &out_q, uint32_t remaining, uint32_t level, R *fb, StatShard *stats)
-{
-    if ((sf & (SF_REFLECTIVE | SF_TRANSPARENT)) == 0 || in_q.cap_sub == 0) return hipSuccess;  // nothing can be queued
-    const dim3 grid((in_q.cap_sub + kRayBlock<R> - 1) / kRayBlock<R>, in_q.sub_mask + 1);
-#define RTX_CALL(SFV)                                                                                   \
-    if constexpr (((SFV) & (SF_REFLECTIVE | SF_TRANSPARENT)) != 0)                                      \
-        hipLaunchKernelGGL((k_bounce<R, SFV | SF_PATTERN>), grid, dim3(kRayBlock<R>), 0, stream, scene, in_q, \
-                           out_q, remaining, level, fb, stats)
-    RTX_SF_SWITCH(sf, RTX_CALL)
-#undef RTX_CALL
     return hipGetLastError();
 }
 

@@ -14,11 +14,15 @@ namespace rtx {
 constexpr uint32_t kBlock = 256;
 // Threads per workgroup of the kernels that take rays from a queue or an array, one ray per
 // thread without a loop (which keeps loop-carried state out of the scalar registers the object
-// records need).  A bounce grid covers the worst-case queue length, so most of its workgroups
-// find nothing and leave: large workgroups make those cheap, small ones fill the chip more
-// evenly.  Measured on the glass and 10k-object scenes, f64 rays (dearer per ray) are best with
-// 128, f32 rays with 256.
-template <typename R> constexpr uint32_t kRayBlock = sizeof(R) == 8 ? 128u : 256u;
+// records need).  Measured on the glass and 10k-object scenes, f64 rays (dearer per ray) are
+// best with 128, f32 rays with 256.
+#ifndef RTX_RAY_BLOCK_F64
+#define RTX_RAY_BLOCK_F64 128u
+#endif
+#ifndef RTX_RAY_BLOCK_F32
+#define RTX_RAY_BLOCK_F32 256u
+#endif
+template <typename R> constexpr uint32_t kRayBlock = sizeof(R) == 8 ? RTX_RAY_BLOCK_F64 : RTX_RAY_BLOCK_F32;
 // The camera kernel runs one wave per workgroup: its waves share nothing, and single waves fill
 // the chip's last round more evenly than groups of four (4K headline frame: 61 -> 58.5 us).
 constexpr uint32_t kCamBlock = 64;
@@ -54,10 +58,6 @@ struct Launch {
     static hipError_t frame_begin(hipStream_t stream, const CameraDev<R> *cam, const SceneDev<R> &scene,
                                   const PrimScene<R> &prim, uint32_t *zero_a, uint32_t n_a, uint32_t *zero_b,
                                   uint32_t n_b);
-    // One recursion level below the primary rays: consume in_q, add weight * lighting into
-    // fb, queue the next level.  The grid covers the worst-case length of every sub-queue.
-    static hipError_t bounce(uint32_t sf, hipStream_t stream, const SceneDev<R> &scene, const QueueDev<R> &in_q,
-                             const QueueDev<R> &out_q, uint32_t remaining, uint32_t level, R *fb, StatShard *stats);
     // Primary rays only (no tracing): out[6*k..] = origin, direction.
     static hipError_t raygen(uint32_t grid, hipStream_t stream, const CameraDev<R> &cam, uint32_t pix_begin,
                              uint32_t n_pix, double *out);
@@ -67,6 +67,18 @@ struct Launch {
     // (c * 255.999) as u8
     static hipError_t quantize(uint32_t grid, hipStream_t stream, const R *rgb, size_t n, uint8_t *out);
 };
+
+// One recursion level below the primary rays: consume in_q, add weight * lighting into fb, queue
+// the next level.  The launch has about resident_blocks workgroups (what the chip holds at
+// once), shared out evenly among the sub-queues; they loop over the rays that exist.
+template <typename R>
+hipError_t launch_bounce(uint32_t sf, hipStream_t stream, const SceneDev<R> &scene, const QueueDev<R> &in_q,
+                         const QueueDev<R> &out_q, uint32_t remaining, uint32_t level, R *fb, StatShard *stats,
+                         uint32_t resident_blocks);
+extern template hipError_t launch_bounce<double>(uint32_t, hipStream_t, const SceneDev<double> &, const QueueDev<double> &,
+                                                 const QueueDev<double> &, uint32_t, uint32_t, double *, StatShard *, uint32_t);
+extern template hipError_t launch_bounce<float>(uint32_t, hipStream_t, const SceneDev<float> &, const QueueDev<float> &,
+                                                const QueueDev<float> &, uint32_t, uint32_t, float *, StatShard *, uint32_t);
 
 // f64 only: intermediate results of one color_at node per ray.
 hipError_t launch_probe(uint32_t sf, uint32_t grid, hipStream_t stream, const SceneDev<double> &scene,

@@ -114,6 +114,7 @@ struct rtx_context {
     size_t workspace_limit = (size_t)8 << 30;
     uint32_t cull_min_objects = 16;  // scenes with at least this many bounded objects get the bounding-sphere tests
     uint32_t blocks_per_cu = 8;
+    uint32_t bounce_blocks = 4096;   // workgroups of one bounce launch: about what the chip holds at once
     std::mutex mu;
     std::vector<std::unique_ptr<Slot>> slots;
 };
@@ -829,8 +830,12 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Slot *slot, hipStrea
         if (timed && c == 0) HIP_TRY(hipEventRecord(slot->ev[3], stream));
         ++launches;
         for (uint32_t L = 1; L <= plan.levels; ++L) {
-            HIP_TRY(Launch<R>::bounce(scene->sf, stream, S, queue_at(L), queue_at(L + 1), max_depth - L, L, fb,
-                                      slot->shards));
+            // With bounding-sphere tests a block's walk is a long chain of dependent fetches whose length
+            // varies widely: those launches get one workgroup per block the queue can hold (the ones past
+            // its length leave at once; measured 6.9 against 7.4 ms on the 10k-object frame), the
+            // others as many workgroups as the chip holds at once.
+            HIP_TRY(launch_bounce<R>(scene->sf, stream, S, queue_at(L), queue_at(L + 1), max_depth - L, L, fb, slot->shards,
+                                     (scene->sf & SF_CULL) ? 0xffffffffu : ctx->bounce_blocks));
             ++launches;
         }
         done += cam ? units * W : units;
@@ -1030,6 +1035,11 @@ int rtx_context_create(int device_id, rtx_context **out)
     if (const char *e = std::getenv("RTX_CULL_MIN_OBJECTS")) {
         int v = std::atoi(e);
         if (v >= 0) ctx->cull_min_objects = (uint32_t)v;
+    }
+    ctx->bounce_blocks = (uint32_t)ctx->cu_count * 16u;
+    if (const char *e = std::getenv("RTX_BOUNCE_BLOCKS")) {
+        int v = std::atoi(e);
+        if (v >= 1) ctx->bounce_blocks = (uint32_t)v;
     }
     if (const char *e = std::getenv("RTX_BLOCKS_PER_CU")) {
         int v = std::atoi(e);

@@ -1,16 +1,18 @@
-"""Register and spill summary of the device kernels: python3 tools_isa.py f64|f32
-Compiles the translation unit to gfx950 assembly under /tmp and prints, per kernel, the VGPR /
+"""Register and spill summary of the device kernels: python3 tools_isa.py f64|f32 [extra compiler flags]
+Compiles the translation units to gfx950 assembly under /tmp and prints, per kernel, the VGPR /
 SGPR / scratch figures and the counts of the instructions that indicate register pressure."""
 import re, subprocess, sys
 
 prec = sys.argv[1] if len(sys.argv) > 1 else "f64"
 contract = "off" if prec == "f64" else "fast"
 extra = [] if prec == "f64" else ["-fno-slp-vectorize"]  # as build.sh compiles the f32 kernels
-asm = "/tmp/render_%s.s" % prec
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=" + contract,
-                "--cuda-device-only", "-S", "-o", asm, "ray-tracer_amd/csrc/render_%s.hip" % prec] + extra + sys.argv[2:],
-               check=True, stderr=subprocess.DEVNULL)
-s = open(asm).read()
+s = ""
+for unit, more in (("render", []), ("bounce", ["-mllvm", "-disable-machine-licm"])):
+    asm = "/tmp/%s_%s.s" % (unit, prec)
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=" + contract,
+                    "--cuda-device-only", "-S", "-o", asm, "ray-tracer_amd/csrc/%s_%s.hip" % (unit, prec)] + extra + more + sys.argv[2:],
+                   check=True, stderr=subprocess.DEVNULL)
+    s += open(asm).read()
 meta = {}
 for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", s, re.S):
     g = lambda k: re.search(k + r"\s+(\S+)", m.group(2)).group(1)
