@@ -112,6 +112,8 @@ _vp = C.c_void_p
 rtx_last_error = _bind("rtx_last_error", C.c_char_p, [])
 rtx_context_create = _bind("rtx_context_create", C.c_int, [C.c_int, C.POINTER(_vp)])
 rtx_context_destroy = _bind("rtx_context_destroy", None, [_vp])
+rtx_context_synchronize = _bind("rtx_context_synchronize", C.c_int, [_vp])
+rtx_context_set_debug_queue_divisor = _bind("rtx_context_set_debug_queue_divisor", C.c_int, [_vp, C.c_uint32])
 rtx_context_set_workspace_limit = _bind("rtx_context_set_workspace_limit", C.c_int, [_vp, C.c_size_t])
 rtx_context_set_cull_threshold = _bind("rtx_context_set_cull_threshold", C.c_int, [_vp, C.c_uint32])
 rtx_scene_upload = _bind("rtx_scene_upload", C.c_int, [_vp, C.POINTER(SceneDesc), C.POINTER(_vp)])
@@ -133,7 +135,8 @@ rtx_quantize_u8_device = _bind("rtx_quantize_u8_device", C.c_int, [_vp, _vp, C.c
 rtx_device_info = _bind("rtx_device_info", C.c_int, [_vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)])
 
 # every symbol include/rtx.h declares
-RTX_SYMBOLS = ["rtx_last_error", "rtx_context_create", "rtx_context_destroy", "rtx_context_set_workspace_limit",
+RTX_SYMBOLS = ["rtx_last_error", "rtx_context_create", "rtx_context_destroy", "rtx_context_synchronize",
+               "rtx_context_set_debug_queue_divisor", "rtx_context_set_workspace_limit",
                "rtx_context_set_cull_threshold",
                "rtx_scene_upload", "rtx_scene_destroy", "rtx_scene_features", "rtx_render", "rtx_render_8bit", "rtx_render_device", "rtx_trace_rays",
                "rtx_probe_rays", "rtx_selfcheck_division", "rtx_generate_rays", "rtx_quantize_u8_device", "rtx_device_info"]
@@ -247,6 +250,12 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def synchronize(self):
+        _check(rtx_context_synchronize(self.h))
+
+    def set_debug_queue_divisor(self, divisor):
+        _check(rtx_context_set_debug_queue_divisor(self.h, divisor))
 
     def set_workspace_limit(self, nbytes):
         _check(rtx_context_set_workspace_limit(self.h, nbytes))

@@ -153,7 +153,7 @@ k_bounce(BounceArgs<R> args_in_kernarg_segment)
         if (valid) {
             nd = trace_node<R, SF, false, kLaneWalk && (SF & SF_CULL) != 0>(A.S, nullptr, ro, rd, A.remaining, [&](const Node<R> &c) {
                 queue_push2(A.out_q, sub, c.has_reflect, c.over_point, c.reflectv, w * c.reflect_factor, c.has_refract,
-                            c.under_point, c.refract_dir, w * c.refract_factor, px_index, A.stats);
+                            c.under_point, c.refract_dir, w * c.refract_factor, px_index);
             });
         }
         count_hits(A.stats, block + sub_in, A.level, valid && nd.hit);

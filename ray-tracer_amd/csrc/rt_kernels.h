@@ -43,8 +43,7 @@ template <typename R> RT_DEV size_t chunk_index(const QueueDev<R> &q, uint32_t j
     return ((size_t)j * (q.sub_mask + 1u) + sub) * q.cap_sub + idx;
 }
 template <typename R>
-RT_DEV void queue_store(const QueueDev<R> &q, uint32_t sub, uint32_t idx, V3<R> o, V3<R> d, R weight, uint32_t pixel,
-                        StatShard *__restrict__ stats)
+RT_DEV void queue_store(const QueueDev<R> &q, uint32_t sub, uint32_t idx, V3<R> o, V3<R> d, R weight, uint32_t pixel)
 {
     if (idx < q.cap_sub) {
         const R v[8] = { o.x, o.y, o.z, d.x, d.y, d.z, weight, pixel_bits_store<R>(pixel) };
@@ -53,7 +52,9 @@ RT_DEV void queue_store(const QueueDev<R> &q, uint32_t sub, uint32_t idx, V3<R> 
         QueueChunk *dst = reinterpret_cast<QueueChunk *>(q.rec);
         for (uint32_t j = 0; j < kEntryChunks<R>; ++j) dst[chunk_index(q, j, sub, idx)] = c[j];
     } else {
-        atomicAdd(&stats->overflow, 1ull);  // cannot happen: queues are sized for the worst case
+        // cannot happen (queues are sized for the worst case); if it does the ray is dropped and
+        // the host reports the frame as failed
+        __hip_atomic_store(q.overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 // Append the children of one color_at node to sub-queue `sub` of the next level: the reflection
@@ -62,7 +63,7 @@ RT_DEV void queue_store(const QueueDev<R> &q, uint32_t sub, uint32_t idx, V3<R> 
 // reflection rays first, then the refraction rays.
 template <typename R>
 RT_DEV void queue_push2(const QueueDev<R> &q, uint32_t sub, bool has1, V3<R> o1, V3<R> d1, R w1, bool has2, V3<R> o2, V3<R> d2,
-                        R w2, uint32_t pixel, StatShard *__restrict__ stats)
+                        R w2, uint32_t pixel)
 {
     const unsigned long long m1 = __ballot(has1), m2 = __ballot(has2);
     if ((m1 | m2) == 0ull) return;
@@ -73,8 +74,8 @@ RT_DEV void queue_push2(const QueueDev<R> &q, uint32_t sub, bool has1, V3<R> o1,
     if (lane == leader) base = atomicAdd(q.count + (size_t)sub * kCountStride, n1 + (uint32_t)__popcll(m2));
     base = __shfl(base, (int)leader);
     const unsigned long long below = (1ull << lane) - 1ull;
-    if (has1) queue_store(q, sub, base + (uint32_t)__popcll(m1 & below), o1, d1, w1, pixel, stats);
-    if (has2) queue_store(q, sub, base + n1 + (uint32_t)__popcll(m2 & below), o2, d2, w2, pixel, stats);
+    if (has1) queue_store(q, sub, base + (uint32_t)__popcll(m1 & below), o1, d1, w1, pixel);
+    if (has2) queue_store(q, sub, base + n1 + (uint32_t)__popcll(m2 & below), o2, d2, w2, pixel);
 }
 
 // Count the shaded hits of this wave: one atomic per wave that has any, spread over shards.
@@ -104,7 +105,7 @@ RT_DEV void primary_ray(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> ro, V
         nd = trace_node<R, SF, CAM, false>(S, CAM ? &P : nullptr, ro, rd, remaining, [&](const Node<R> &c) {
             if constexpr ((SF & (SF_REFLECTIVE | SF_TRANSPARENT)) != 0)
                 queue_push2(out_q, sub, c.has_reflect, c.over_point, c.reflectv, c.reflect_factor, c.has_refract, c.under_point,
-                            c.refract_dir, c.refract_factor, k, stats);
+                            c.refract_dir, c.refract_factor, k);
         });
         R *px = fb + (size_t)k * 3;
         px[0] = nd.lighting.x;

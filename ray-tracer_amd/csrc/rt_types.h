@@ -185,6 +185,7 @@ struct QueueDev {
     uint32_t *count;   // length of sub-queue q at count[q * kCountStride]
     uint32_t cap_sub;  // entries per sub-queue (0: nothing may be appended)
     uint32_t sub_mask; // n_sub - 1, n_sub a power of two
+    uint32_t *overflow; // set to 1 when an append finds its sub-queue full (host memory the device can write)
 };
 
 // Per-level counters, one block of shards per render call (summed on the host).
@@ -193,8 +194,7 @@ constexpr uint32_t kSpreadLanes = 1024u * 4u * 64u;
 constexpr int kStatShards = 256;
 struct StatShard {
     unsigned long long hits[8];  // shaded hits (= is_shadowed calls) per recursion level
-    unsigned long long overflow;
-    unsigned long long pad[7];
+    unsigned long long pad[8];
 };
 
 }  // namespace rtx

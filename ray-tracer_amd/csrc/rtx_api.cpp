@@ -50,26 +50,34 @@ int fail(int code, const char *fmt, ...)
 
 constexpr uint32_t kMaxLevels = 8;  // rtx_stats.rays_per_level entries; max_depth <= 7
 
+// Device memory the kernels of one frame use beyond the scene tables and the framebuffer.  A
+// slot's workspace grows on demand (hipMalloc); the allocation-free entry point carves a fixed one
+// out of the file-scope device array of scratch.hip.
+struct Workspace {
+    void *queues = nullptr;     // both ping-pong ray queues
+    size_t queue_bytes = 0;
+    uint32_t *counts = nullptr; // sub-queue length counters: per chunk, per level, per sub-queue
+    size_t counts_n = 0;        // in words
+    void *prim = nullptr;       // primary-ray tables of the scene and camera origin below
+    size_t prim_bytes = 0;
+    StatShard *shards = nullptr;
+    bool fixed = false;         // not ours to grow or free
+    uint64_t prim_scene = 0;    // rtx_scene::serial the tables were built from (0: none)
+    double prim_origin[3] = { 0, 0, 0 };
+    size_t prim_elem = 0;       // sizeof(R) of the tables
+    uint32_t n_sub = 1;         // sub-queues per queue of the last frame enqueued
+};
+
 // Scratch of one in-flight render call.  A context keeps a pool of these so that calls from
 // different host threads overlap on the device instead of serialising.
 struct Slot {
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
-    void *queues = nullptr;     // both ping-pong ray queues
-    size_t queue_bytes = 0;
+    Workspace ws;
     void *fb = nullptr;         // device framebuffer for host-output calls
     size_t fb_bytes = 0;
-    void *aux = nullptr;        // ray upload / probe output
+    void *aux = nullptr;        // ray upload / probe output / 8-bit pixels
     size_t aux_bytes = 0;
-    void *prim = nullptr;       // primary-ray tables of the scene and camera origin below
-    size_t prim_bytes = 0;
-    uint64_t prim_scene = 0;    // rtx_scene::serial the tables were built from (0: none)
-    double prim_origin[3] = { 0, 0, 0 };
-    size_t prim_elem = 0;       // sizeof(R) of the tables
-    uint32_t *counts = nullptr; // sub-queue length counters: per chunk, per level, per sub-queue
-    size_t counts_n = 0;
-    uint32_t n_sub = 1;         // sub-queues per queue of the last frame enqueued
-    StatShard *shards = nullptr;
     hipEvent_t done = nullptr;  // recorded when a call returns with work still in flight
     bool pending = false;
     bool busy = false;
@@ -82,11 +90,10 @@ struct Slot {
     void release()
     {
         if (stream) (void)hipStreamSynchronize(stream);
-        for (void *p : { queues, fb, aux, prim, (void *)counts, (void *)shards })
+        for (void *p : { ws.queues, fb, aux, ws.prim, (void *)ws.counts, (void *)ws.shards })
             if (p) (void)hipFree(p);
-        queues = fb = aux = prim = nullptr;
-        counts = nullptr;
-        shards = nullptr;
+        ws = Workspace();
+        fb = aux = nullptr;
         if (done) (void)hipEventDestroy(done);
         done = nullptr;
         for (int k = 0; k < 2; ++k) {
@@ -115,6 +122,9 @@ struct rtx_context {
     uint32_t cull_min_objects = 16;  // scenes with at least this many bounded objects get the bounding-sphere tests
     uint32_t blocks_per_cu = 8;
     uint32_t bounce_blocks = 4096;   // workgroups of one bounce launch: about what the chip holds at once
+    uint32_t *overflow_host = nullptr;  // pinned word the kernels set when a ray queue overflows
+    uint32_t *overflow_dev = nullptr;   // the same word as the device addresses it
+    uint32_t debug_queue_divisor = 1;   // tests: queues this many times smaller than planned
     std::mutex mu;
     std::vector<std::unique_ptr<Slot>> slots;
 };
@@ -159,7 +169,7 @@ int slot_acquire(rtx_context *ctx, Slot **out)
         HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
         for (auto &e : s->ev) HIP_TRY(hipEventCreate(&e));
         HIP_TRY(hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
-        HIP_TRY(hipMalloc((void **)&s->shards, sizeof(StatShard) * kStatShards));
+        HIP_TRY(hipMalloc((void **)&s->ws.shards, sizeof(StatShard) * kStatShards));
         return RTX_OK;
     };
     const int rc = build();
@@ -708,7 +718,7 @@ void size_queues(uint32_t sf, uint32_t levels, uint32_t hsize, uint64_t units, F
 // Split the frame into chunks of whole rows (or of rays, hsize = 0) so that both ping-pong
 // queues, sized for the worst case, fit the workspace limit.
 template <typename R>
-int plan_frame(const rtx_context *ctx, uint32_t sf, uint32_t max_depth, uint32_t hsize, uint64_t n_units, FramePlan *p)
+int plan_frame(size_t limit, uint32_t sf, uint32_t max_depth, uint32_t hsize, uint64_t n_units, FramePlan *p)
 {
     if (max_depth >= kMaxLevels) return fail(RTX_ERR_INVALID, "max_depth %u is not supported (limit %u)", max_depth, kMaxLevels - 1);
     const bool secondary = children_per_hit(sf) != 0 && max_depth > 0;
@@ -717,7 +727,7 @@ int plan_frame(const rtx_context *ctx, uint32_t sf, uint32_t max_depth, uint32_t
     const uint64_t max_units = hsize ? std::max<uint64_t>(1, 0x7fffff00ull / hsize) : 0x7fffff00ull;
     auto fits = [&](uint64_t units) {
         size_queues<R>(sf, levels, hsize, units, p);
-        if (p->bytes > ctx->workspace_limit) return false;
+        if (p->bytes > limit) return false;
         for (uint32_t L = 1; L <= levels; ++L)
             if (p->cap_sub[L] > 0x7fffff00ull) return false;  // sub-queue slots are indexed with 32 bits
         return true;
@@ -735,31 +745,54 @@ int plan_frame(const rtx_context *ctx, uint32_t sf, uint32_t max_depth, uint32_t
     return RTX_OK;
 }
 
-// Enqueue every kernel of one frame (or ray batch) on the slot's stream.  Camera renders cover
-// n_units rows starting at row first_row; batches cover n_units rays of d_rays.
+// A queue overflow drops rays: the frame it happened in is wrong.  The kernels report it through
+// a word of pinned host memory, which every later call on the context looks at.
+int check_overflow(rtx_context *ctx)
+{
+    if (ctx->overflow_host && __atomic_load_n(ctx->overflow_host, __ATOMIC_ACQUIRE) != 0u) {
+        __atomic_store_n(ctx->overflow_host, 0u, __ATOMIC_RELEASE);
+        return fail(RTX_ERR_DEVICE, "secondary-ray queue overflow in an earlier frame of this context (internal sizing error): "
+                                    "that frame is incomplete");
+    }
+    return RTX_OK;
+}
+
+// Enqueue every kernel of one frame (or ray batch) on `stream`.  Camera renders cover n_units rows
+// starting at row first_row; batches cover n_units rays of d_rays.  `ev` (four events) is only
+// used when timed.
 template <typename R>
-int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Slot *slot, hipStream_t stream, const CameraDev<R> *cam,
-                  const double *d_rays, uint32_t first_row, uint64_t n_units, uint32_t max_depth, R *d_fb,
+int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Workspace &ws, hipEvent_t *ev, hipStream_t stream,
+                  const CameraDev<R> *cam, const double *d_rays, uint32_t first_row, uint64_t n_units, uint32_t max_depth, R *d_fb,
                   rtx_progress_fn progress, void *user, bool timed, uint32_t *n_chunks_out, uint32_t *n_launch_out)
 {
     FramePlan plan;
     const uint32_t W = cam ? cam->hsize : 0;
-    int rc = plan_frame<R>(ctx, scene->sf, max_depth, W, n_units, &plan);
+    int rc = plan_frame<R>(ws.fixed ? ws.queue_bytes : ctx->workspace_limit, scene->sf, max_depth, W, n_units, &plan);
     if (rc) return rc;
+    if (ctx->debug_queue_divisor > 1)
+        for (auto &c : plan.cap_sub) c = c ? std::max<uint64_t>(1, c / ctx->debug_queue_divisor) : 0;
     const uint32_t n_chunks = (uint32_t)((n_units + plan.chunk_units - 1) / plan.chunk_units);
-    rc = grow(&slot->queues, &slot->queue_bytes, plan.bytes);
-    if (rc) return rc;
     const size_t counts_per_chunk = (size_t)(kMaxLevels + 1) * plan.n_sub * kCountStride;
     const size_t counts_need = (size_t)std::max<uint32_t>(n_chunks, 1) * counts_per_chunk;
-    if (counts_need > slot->counts_n) {
-        if (slot->counts) HIP_TRY(hipFree(slot->counts));
-        slot->counts = nullptr;
-        slot->counts_n = 0;
-        HIP_TRY(hipMalloc((void **)&slot->counts, counts_need * sizeof(uint32_t)));
-        slot->counts_n = counts_need;
+    if (ws.fixed) {
+        if (plan.bytes > ws.queue_bytes)
+            return fail(RTX_ERR_INVALID, "frame needs %zu bytes of ray queues; the fixed workspace holds %zu", plan.bytes, ws.queue_bytes);
+        if (counts_need > ws.counts_n)
+            return fail(RTX_ERR_INVALID, "frame too large for the fixed workspace: %u row chunks need %zu counter words, it holds %zu",
+                        n_chunks, counts_need, ws.counts_n);
+    } else {
+        rc = grow(&ws.queues, &ws.queue_bytes, plan.bytes);
+        if (rc) return rc;
+        if (counts_need > ws.counts_n) {
+            if (ws.counts) HIP_TRY(hipFree(ws.counts));
+            ws.counts = nullptr;
+            ws.counts_n = 0;
+            HIP_TRY(hipMalloc((void **)&ws.counts, counts_need * sizeof(uint32_t)));
+            ws.counts_n = counts_need;
+        }
     }
-    slot->n_sub = plan.n_sub;
-    if (timed) HIP_TRY(hipEventRecord(slot->ev[0], stream));
+    ws.n_sub = plan.n_sub;
+    if (timed) HIP_TRY(hipEventRecord(ev[0], stream));
 
     // primary-ray tables: one entry per object, rebuilt every frame from the camera origin
     PrimScene<R> prim;
@@ -770,11 +803,18 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Slot *slot, hipStrea
         const size_t b_sph = pad(SD.n_sph * sizeof(PrimSphereRec<R>)), b_pln = pad(SD.n_pln * sizeof(PrimPlaneRec<R>)),
                      b_cub = pad(SD.n_cub * sizeof(PrimCubeRec<R>)), b_cyl = pad(SD.n_cyl * sizeof(PrimCappedRec<R>)),
                      b_con = pad(SD.n_con * sizeof(PrimCappedRec<R>));
-        const void *before = slot->prim;
-        rc = grow(&slot->prim, &slot->prim_bytes, b_sph + b_pln + b_cub + b_cyl + b_con + 256);
-        if (rc) return rc;
-        if (slot->prim != before) slot->prim_scene = 0;
-        char *base = (char *)slot->prim;
+        const size_t need = b_sph + b_pln + b_cub + b_cyl + b_con + 256;
+        if (ws.fixed) {
+            if (need > ws.prim_bytes)
+                return fail(RTX_ERR_INVALID, "scene too large for the fixed workspace: its primary-ray tables need %zu bytes, it holds %zu",
+                            need, ws.prim_bytes);
+        } else {
+            const void *before = ws.prim;
+            rc = grow(&ws.prim, &ws.prim_bytes, need);
+            if (rc) return rc;
+            if (ws.prim != before) ws.prim_scene = 0;
+        }
+        char *base = (char *)ws.prim;
         prim.sph = (const PrimSphereRec<R> *)base;
         prim.pln = (const PrimPlaneRec<R> *)(base + b_sph);
         prim.cub = (const PrimCubeRec<R> *)(base + b_sph + b_pln);
@@ -786,21 +826,21 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Slot *slot, hipStrea
     // A frame with no secondary rays whose caller does not read the counters needs neither when the
     // tables already hold this scene seen from this camera origin: rendering the same view again
     // (or another row range of it) is then one launch.
-    const bool tables_current = cam && SD.n && slot->prim_scene == scene->serial && slot->prim_elem == sizeof(R) &&
-                                slot->prim_origin[0] == (double)cam->origin[0] && slot->prim_origin[1] == (double)cam->origin[1] &&
-                                slot->prim_origin[2] == (double)cam->origin[2];
+    const bool tables_current = cam && SD.n && ws.prim_scene == scene->serial && ws.prim_elem == sizeof(R) &&
+                                ws.prim_origin[0] == (double)cam->origin[0] && ws.prim_origin[1] == (double)cam->origin[1] &&
+                                ws.prim_origin[2] == (double)cam->origin[2];
     const bool no_children = (scene->sf & (SF_REFLECTIVE | SF_TRANSPARENT)) == 0;  // nothing is ever queued
     if (!(tables_current && no_children && plan.levels == 0 && !timed)) {
-        HIP_TRY(Launch<R>::frame_begin(stream, cam, SD, prim, slot->counts, (uint32_t)counts_need, (uint32_t *)slot->shards,
+        HIP_TRY(Launch<R>::frame_begin(stream, cam, SD, prim, ws.counts, (uint32_t)counts_need, (uint32_t *)ws.shards,
                                        (uint32_t)(sizeof(StatShard) * kStatShards / sizeof(uint32_t))));
         if (cam && SD.n) {
-            slot->prim_scene = scene->serial;
-            slot->prim_elem = sizeof(R);
-            for (int k = 0; k < 3; ++k) slot->prim_origin[k] = (double)cam->origin[k];
+            ws.prim_scene = scene->serial;
+            ws.prim_elem = sizeof(R);
+            for (int k = 0; k < 3; ++k) ws.prim_origin[k] = (double)cam->origin[k];
         }
     }
 
-    R *q_odd = (R *)slot->queues;
+    R *q_odd = (R *)ws.queues;
     R *q_even = q_odd + plan.odd_entries * 8;
     const SceneDev<R> &S = scene_dev<R>(scene);
     uint32_t launches = 0;
@@ -808,33 +848,34 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Slot *slot, hipStrea
     for (uint32_t c = 0; c < n_chunks; ++c) {
         const uint64_t u0 = (uint64_t)c * plan.chunk_units;
         const uint64_t units = std::min<uint64_t>(plan.chunk_units, n_units - u0);
-        uint32_t *counts = slot->counts + (size_t)c * counts_per_chunk;
+        uint32_t *counts = ws.counts + (size_t)c * counts_per_chunk;
         auto queue_at = [&](uint32_t level) {
             QueueDev<R> q;
             q.rec = (level & 1) ? q_odd : q_even;
             q.count = counts + (size_t)level * plan.n_sub * kCountStride;
             q.cap_sub = level <= plan.levels ? (uint32_t)plan.cap_sub[level] : 0u;
             q.sub_mask = plan.n_sub - 1;
+            q.overflow = ctx->overflow_dev;
             return q;
         };
         const uint64_t k0 = cam ? u0 * W : u0;  // first primary ray of the chunk
         R *fb = d_fb + k0 * 3;
-        if (timed && c == 0) HIP_TRY(hipEventRecord(slot->ev[2], stream));
+        if (timed && c == 0) HIP_TRY(hipEventRecord(ev[2], stream));
         if (cam) {
             HIP_TRY(Launch<R>::primary_camera(scene->sf, stream, *cam, S, prim, first_row + (uint32_t)u0, (uint32_t)units,
-                                              max_depth, fb, queue_at(1), slot->shards));
+                                              max_depth, fb, queue_at(1), ws.shards));
         } else {
             HIP_TRY(Launch<R>::primary_rays(scene->sf, stream, S, d_rays + k0 * 6, (uint32_t)units, max_depth, fb, queue_at(1),
-                                            slot->shards));
+                                            ws.shards));
         }
-        if (timed && c == 0) HIP_TRY(hipEventRecord(slot->ev[3], stream));
+        if (timed && c == 0) HIP_TRY(hipEventRecord(ev[3], stream));
         ++launches;
         for (uint32_t L = 1; L <= plan.levels; ++L) {
             // With bounding-sphere tests a block's walk is a long chain of dependent fetches whose length
             // varies widely: those launches get one workgroup per block the queue can hold (the ones past
             // its length leave at once; measured 6.9 against 7.4 ms on the 10k-object frame), the
             // others as many workgroups as the chip holds at once.
-            HIP_TRY(launch_bounce<R>(scene->sf, stream, S, queue_at(L), queue_at(L + 1), max_depth - L, L, fb, slot->shards,
+            HIP_TRY(launch_bounce<R>(scene->sf, stream, S, queue_at(L), queue_at(L + 1), max_depth - L, L, fb, ws.shards,
                                      (scene->sf & SF_CULL) ? 0xffffffffu : ctx->bounce_blocks));
             ++launches;
         }
@@ -844,30 +885,30 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Slot *slot, hipStrea
             progress(done, user);
         }
     }
-    if (timed) HIP_TRY(hipEventRecord(slot->ev[1], stream));
+    if (timed) HIP_TRY(hipEventRecord(ev[1], stream));
     if (n_chunks_out) *n_chunks_out = n_chunks;
     if (n_launch_out) *n_launch_out = launches;
     return RTX_OK;
 }
 
 // After the stream has drained: gather counters into stats; report a queue overflow.
-int collect_stats(Slot *slot, uint32_t n_chunks, uint64_t n_primary, bool timed, rtx_stats *stats)
+int collect_stats(rtx_context *ctx, Slot *slot, uint32_t n_chunks, uint64_t n_primary, bool timed, rtx_stats *stats)
 {
-    std::vector<StatShard> shards(kStatShards);
-    HIP_TRY(hipMemcpy(shards.data(), slot->shards, sizeof(StatShard) * kStatShards, hipMemcpyDeviceToHost));
-    const size_t counts_per_chunk = (size_t)(kMaxLevels + 1) * slot->n_sub * kCountStride;
-    std::vector<uint32_t> counts((size_t)n_chunks * counts_per_chunk);
-    HIP_TRY(hipMemcpy(counts.data(), slot->counts, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    uint64_t overflow = 0;
-    for (auto &s : shards) overflow += s.overflow;
-    if (overflow) return fail(RTX_ERR_DEVICE, "secondary-ray queue overflow (internal sizing error)");
+    int rc = check_overflow(ctx);
+    if (rc) return rc;
     if (!stats) return RTX_OK;
+    const Workspace &ws = slot->ws;
+    std::vector<StatShard> shards(kStatShards);
+    HIP_TRY(hipMemcpy(shards.data(), ws.shards, sizeof(StatShard) * kStatShards, hipMemcpyDeviceToHost));
+    const size_t counts_per_chunk = (size_t)(kMaxLevels + 1) * ws.n_sub * kCountStride;
+    std::vector<uint32_t> counts((size_t)n_chunks * counts_per_chunk);
+    HIP_TRY(hipMemcpy(counts.data(), ws.counts, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     std::memset(stats->rays_per_level, 0, sizeof stats->rays_per_level);
     stats->rays_per_level[0] = n_primary;
     for (uint32_t c = 0; c < n_chunks; ++c)
         for (uint32_t L = 1; L < kMaxLevels; ++L)
-            for (uint32_t q = 0; q < slot->n_sub; ++q)
-                stats->rays_per_level[L] += counts[c * counts_per_chunk + ((size_t)L * slot->n_sub + q) * kCountStride];
+            for (uint32_t q = 0; q < ws.n_sub; ++q)
+                stats->rays_per_level[L] += counts[c * counts_per_chunk + ((size_t)L * ws.n_sub + q) * kCountStride];
     stats->color_rays = 0;
     for (uint32_t L = 0; L < kMaxLevels; ++L) stats->color_rays += stats->rays_per_level[L];
     stats->shadow_rays = 0;
@@ -902,10 +943,12 @@ int render_impl(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_desc 
 {
     // channels8 != 0: an RTX_PIXELS_* format; host_out receives 8-bit pixels instead of R values
     const auto t0 = std::chrono::steady_clock::now();
+    int rc = check_overflow(ctx);
+    if (rc) return rc;
     DeviceGuard guard(ctx->device);
     if (!guard.ok) return fail(RTX_ERR_DEVICE, "hipSetDevice(%d) failed", ctx->device);
     SlotLease lease(ctx);
-    int rc = slot_acquire(ctx, &lease.slot);
+    rc = slot_acquire(ctx, &lease.slot);
     if (rc) return rc;
     Slot *slot = lease.slot;
     const uint64_t W = cam->hsize;
@@ -923,9 +966,11 @@ int render_impl(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_desc 
     }
     const CameraDev<R> cd = make_camera<R>(cam);
     uint32_t n_chunks = 0, n_launch = 0;
-    const bool sync = host_out != nullptr || stats != nullptr;
-    rc = enqueue_frame<R>(ctx, scene, slot, stream, &cd, nullptr, row_begin, row_end - row_begin, max_depth, d_fb,
-                          progress, user, sync, &n_chunks, &n_launch);
+    // without a stream of the caller's there is nothing the caller could wait on: the call waits itself
+    const bool sync = host_out != nullptr || stats != nullptr || user_stream == nullptr;
+    const bool timed = stats != nullptr;
+    rc = enqueue_frame<R>(ctx, scene, slot->ws, slot->ev, stream, &cd, nullptr, row_begin, row_end - row_begin, max_depth, d_fb,
+                          progress, user, timed, &n_chunks, &n_launch);
     if (rc) return rc;
     if (!sync) {
         HIP_TRY(hipEventRecord(slot->done, stream));
@@ -946,7 +991,7 @@ int render_impl(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_desc 
     }
     HIP_TRY(hipStreamSynchronize(stream));
     slot_settled(slot);
-    rc = collect_stats(slot, n_chunks, n_pix, true, stats);
+    rc = collect_stats(ctx, slot, n_chunks, n_pix, timed, stats);
     if (rc) return rc;
     if (stats) {
         stats->n_chunks = n_chunks;
@@ -979,7 +1024,7 @@ int trace_impl(rtx_context *ctx, const rtx_scene *scene, const double *rays, siz
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(slot->aux, rays, ray_bytes, hipMemcpyHostToDevice, stream));
     uint32_t n_chunks = 0, n_launch = 0;
-    rc = enqueue_frame<R>(ctx, scene, slot, stream, nullptr, (const double *)slot->aux, 0, n, max_depth, (R *)slot->fb,
+    rc = enqueue_frame<R>(ctx, scene, slot->ws, slot->ev, stream, nullptr, (const double *)slot->aux, 0, n, max_depth, (R *)slot->fb,
                           nullptr, nullptr, true, &n_chunks, &n_launch);
     if (rc) return rc;
     std::vector<R> tmp;
@@ -993,7 +1038,7 @@ int trace_impl(rtx_context *ctx, const rtx_scene *scene, const double *rays, siz
     slot_settled(slot);
     if (sizeof(R) != sizeof(double))
         for (size_t i = 0; i < n * 3; ++i) out_rgb[i] = (double)tmp[i];
-    rc = collect_stats(slot, n_chunks, n, true, stats);
+    rc = collect_stats(ctx, slot, n_chunks, n, true, stats);
     if (rc) return rc;
     if (stats) {
         stats->n_chunks = n_chunks;
@@ -1045,6 +1090,17 @@ int rtx_context_create(int device_id, rtx_context **out)
         int v = std::atoi(e);
         if (v >= 1 && v <= 64) ctx->blocks_per_cu = (uint32_t)v;
     }
+    {
+        DeviceGuard guard(device_id);
+        if (!guard.ok) return fail(RTX_ERR_DEVICE, "hipSetDevice(%d) failed", device_id);
+        HIP_TRY(hipHostMalloc((void **)&ctx->overflow_host, 256, hipHostMallocMapped));
+        *ctx->overflow_host = 0u;
+        const hipError_t e = hipHostGetDevicePointer((void **)&ctx->overflow_dev, ctx->overflow_host, 0);
+        if (e != hipSuccess) {
+            (void)hipHostFree(ctx->overflow_host);
+            return fail(RTX_ERR_DEVICE, "hipHostGetDevicePointer failed: %s", hipGetErrorString(e));
+        }
+    }
     *out = ctx.release();
     return RTX_OK;
 }
@@ -1055,8 +1111,33 @@ void rtx_context_destroy(rtx_context *ctx)
     {
         DeviceGuard guard(ctx->device);
         for (auto &s : ctx->slots) s->release();
+        if (ctx->overflow_host) (void)hipHostFree(ctx->overflow_host);
     }
     delete ctx;
+}
+
+int rtx_context_synchronize(rtx_context *ctx)
+{
+    if (!ctx) return fail(RTX_ERR_INVALID, "ctx is NULL");
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return fail(RTX_ERR_DEVICE, "hipSetDevice(%d) failed", ctx->device);
+    std::vector<hipEvent_t> waits;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        for (auto &s : ctx->slots)
+            if (s->pending) waits.push_back(s->done);
+    }
+    for (hipEvent_t e : waits) HIP_TRY(hipEventSynchronize(e));
+    return check_overflow(ctx);
+}
+
+int rtx_context_set_debug_queue_divisor(rtx_context *ctx, uint32_t divisor)
+{
+    if (!ctx) return fail(RTX_ERR_INVALID, "ctx is NULL");
+    if (divisor == 0) return fail(RTX_ERR_INVALID, "divisor must be at least 1");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->debug_queue_divisor = divisor;
+    return RTX_OK;
 }
 
 int rtx_context_set_workspace_limit(rtx_context *ctx, size_t bytes)
