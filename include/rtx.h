@@ -205,6 +205,26 @@ int rtx_render_device(rtx_context *ctx, const rtx_scene *scene, const rtx_camera
                       void *stream, rtx_stats *stats);
 
 /*
+ * rtx_render_device for callers that cannot allocate: code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  The call
+ * allocates and frees nothing, on the device or through any library: the counters, the per-frame
+ * primary-ray tables and the secondary-ray queues that rtx_render_device keeps in memory it
+ * allocates live in a file-scope device array of 256 MiB that every GPU the library runs on holds
+ * from the moment its code is loaded there.  The kernels are enqueued on `stream` (NULL: the
+ * null stream) and the call returns at once; there are no statistics and no progress calls.
+ * Frames are split into row chunks whose queues fit the array; a frame that needs more chunks
+ * than the array has counters for (32 MiB of them), or a scene whose primary-ray tables exceed
+ * 8 MiB (about 60 000 objects), is refused with RTX_ERR_INVALID and nothing is enqueued: an 8K
+ * frame of a scene with glass at depth 5 fits, at depth 7 it does not.
+ * All calls on one GPU share that GPU's array: calls that overlap in time on one GPU race with
+ * each other (calls on the same stream do not overlap).  Every call clears what it needs to find
+ * zero, whatever the previous call left behind.
+ */
+int rtx_render_device_noalloc(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_desc *camera, uint32_t max_depth,
+                              int precision, uint32_t row_begin, uint32_t row_end, void *d_out_rgb, size_t out_bytes,
+                              void *stream);
+
+/*
  * Batch form of World::color_at (src/scenes/world.rs:136-144): rays is n x 6 doubles
  * (origin xyz, direction xyz), out_rgb is n x 3 doubles (filled from the f32 result when
  * precision is RTX_F32).

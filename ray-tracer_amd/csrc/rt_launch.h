@@ -80,6 +80,11 @@ extern template hipError_t launch_bounce<double>(uint32_t, hipStream_t, const Sc
 extern template hipError_t launch_bounce<float>(uint32_t, hipStream_t, const SceneDev<float> &, const QueueDev<float> &,
                                                 const QueueDev<float> &, uint32_t, uint32_t, float *, StatShard *, uint32_t);
 
+// Size of the file-scope device array behind rtx_render_device_noalloc (scratch.hip), and its
+// device address on the current device.
+constexpr size_t kScratchBytes = (size_t)256 << 20;
+hipError_t scratch_address(void **ptr, size_t *bytes);
+
 // f64 only: intermediate results of one color_at node per ray.
 hipError_t launch_probe(uint32_t sf, uint32_t grid, hipStream_t stream, const SceneDev<double> &scene,
                         const double *rays, uint32_t n, rtx_probe *out);

@@ -122,6 +122,8 @@ struct rtx_context {
     uint32_t cull_min_objects = 16;  // scenes with at least this many bounded objects get the bounding-sphere tests
     uint32_t blocks_per_cu = 8;
     uint32_t bounce_blocks = 4096;   // workgroups of one bounce launch: about what the chip holds at once
+    void *scratch = nullptr;         // this device's copy of the file-scope array of scratch.hip
+    size_t scratch_bytes = 0;
     uint32_t *overflow_host = nullptr;  // pinned word the kernels set when a ray queue overflows
     uint32_t *overflow_dev = nullptr;   // the same word as the device addresses it
     uint32_t debug_queue_divisor = 1;   // tests: queues this many times smaller than planned
@@ -1048,6 +1050,36 @@ int trace_impl(rtx_context *ctx, const rtx_scene *scene, const double *rays, siz
     return RTX_OK;
 }
 
+// Layout of the file-scope device array for one frame of rtx_render_device_noalloc: hit counters,
+// queue length counters, primary-ray tables, then both ray queues.
+constexpr size_t kNoAllocCountBytes = (size_t)32 << 20;
+constexpr size_t kNoAllocPrimBytes = (size_t)8 << 20;
+
+template <typename R>
+int render_noalloc(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_desc *cam, uint32_t max_depth, uint32_t row_begin,
+                          uint32_t row_end, void *d_out, hipStream_t stream)
+{
+    Workspace ws;
+    char *base = (char *)ctx->scratch;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char *p = base + off;
+        off += (bytes + 255) & ~(size_t)255;
+        return p;
+    };
+    ws.fixed = true;
+    ws.shards = (StatShard *)take(sizeof(StatShard) * kStatShards);
+    ws.counts = (uint32_t *)take(kNoAllocCountBytes);
+    ws.counts_n = kNoAllocCountBytes / sizeof(uint32_t);
+    ws.prim = take(kNoAllocPrimBytes);
+    ws.prim_bytes = kNoAllocPrimBytes;
+    ws.queues = base + off;
+    ws.queue_bytes = ctx->scratch_bytes - off;
+    const CameraDev<R> cd = make_camera<R>(cam);
+    return enqueue_frame<R>(ctx, scene, ws, nullptr, stream, &cd, nullptr, row_begin, row_end - row_begin, max_depth, (R *)d_out,
+                            nullptr, nullptr, false, nullptr, nullptr);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1093,6 +1125,8 @@ int rtx_context_create(int device_id, rtx_context **out)
     {
         DeviceGuard guard(device_id);
         if (!guard.ok) return fail(RTX_ERR_DEVICE, "hipSetDevice(%d) failed", device_id);
+        // this device's copy of the file-scope array that rtx_render_device_noalloc works in
+        HIP_TRY(scratch_address(&ctx->scratch, &ctx->scratch_bytes));
         HIP_TRY(hipHostMalloc((void **)&ctx->overflow_host, 256, hipHostMallocMapped));
         *ctx->overflow_host = 0u;
         const hipError_t e = hipHostGetDevicePointer((void **)&ctx->overflow_dev, ctx->overflow_host, 0);
@@ -1312,6 +1346,28 @@ int rtx_render_device(rtx_context *ctx, const rtx_scene *scene, const rtx_camera
     if (precision == RTX_F64)
         return render_impl<double>(ctx, scene, camera, max_depth, row_begin, row_end, nullptr, d_out_rgb, (hipStream_t)stream, nullptr, nullptr, stats);
     return render_impl<float>(ctx, scene, camera, max_depth, row_begin, row_end, nullptr, d_out_rgb, (hipStream_t)stream, nullptr, nullptr, stats);
+}
+
+int rtx_render_device_noalloc(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_desc *camera, uint32_t max_depth,
+                              int precision, uint32_t row_begin, uint32_t row_end, void *d_out_rgb, size_t out_bytes, void *stream)
+{
+    if (!ctx || !scene || scene->ctx != ctx) return fail(RTX_ERR_INVALID, "scene does not belong to this context");
+    int rc = check_camera(camera, row_begin, row_end);
+    if (rc) return rc;
+    if (precision != RTX_F64 && precision != RTX_F32) return fail(RTX_ERR_INVALID, "unknown precision %d", precision);
+    const size_t elem = precision == RTX_F64 ? sizeof(double) : sizeof(float);
+    const size_t need = (size_t)(row_end - row_begin) * camera->hsize * 3 * elem;
+    if (need && (!d_out_rgb || out_bytes < need)) return fail(RTX_ERR_INVALID, "output buffer holds %zu bytes, %zu needed", out_bytes, need);
+    if (!ctx->scratch || ctx->scratch_bytes < kNoAllocCountBytes + kNoAllocPrimBytes + ((size_t)1 << 20))
+        return fail(RTX_ERR_DEVICE, "the context has no fixed workspace");
+    rc = check_overflow(ctx);
+    if (rc) return rc;
+    if (need == 0) return RTX_OK;
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return fail(RTX_ERR_DEVICE, "hipSetDevice(%d) failed", ctx->device);
+    if (precision == RTX_F64)
+        return render_noalloc<double>(ctx, scene, camera, max_depth, row_begin, row_end, d_out_rgb, (hipStream_t)stream);
+    return render_noalloc<float>(ctx, scene, camera, max_depth, row_begin, row_end, d_out_rgb, (hipStream_t)stream);
 }
 
 int rtx_trace_rays(rtx_context *ctx, const rtx_scene *scene, const double *rays, size_t n, uint32_t max_depth, int precision,
