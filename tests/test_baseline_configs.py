@@ -1,0 +1,141 @@
+"""The benchmark configurations at their defining sizes: the 10 002-object scene, the default
+world at 3840x2160 on the f32 path, and the 7680x4320 multi-light glass frame assembled from
+the row tiles eight GPUs would render.  Each is compared with the oracle on a sample (the oracle
+needs seconds per thousand rays at these sizes) and checked whole through properties."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import hiprt
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-9
+
+
+def _camera_rays(orc, ocam, xs, ys):
+    return np.array([orc.ray_for_pixel(ocam, int(x), int(y)) for x, y in zip(xs, ys)])
+
+
+def test_ten_thousand_objects_at_full_size(orc, rta):
+    """N = 10 002 (20 group spheres over 313 clusters of spheres alone): colours of 3 000 camera
+    rays and 2 000 rays shot through the cloud at random against the oracle's color_at, the
+    intermediate results of 600 of them bit for bit, and the 4K frame's pixels and counters."""
+    from ray_tracer_amd import scenes
+    W, H = 3840, 2160
+    gw, gcam = scenes.random_scene(rta.api, hsize=W, vsize=H)
+    ow, ocam = scenes.random_scene(orc.api, hsize=W, vsize=H)
+    assert len(gw) == 10002
+    rng = np.random.default_rng(2024)
+    xs, ys = rng.integers(0, W, 3000), rng.integers(0, H, 3000)
+    cam_rays = _camera_rays(orc, ocam, xs, ys)
+    o = np.stack([rng.uniform(-45, 45, 2000), rng.uniform(0.2, 28, 2000), rng.uniform(-10, 125, 2000)], axis=1)
+    target = np.stack([rng.uniform(-40, 40, 2000), rng.uniform(0.5, 25, 2000), rng.uniform(-5, 120, 2000)], axis=1)
+    d = target - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([cam_rays, np.concatenate([o, d], axis=1)])
+    g_cnt, o_cnt = [0, 0], [0, 0]
+    got = rta.color_at(gw, rays, 5, counters=g_cnt)
+    want = orc.color_at(ow, rays, 5, counters=o_cnt)
+    assert np.abs(got - want).max() <= TOL
+    assert g_cnt == o_cnt, "ray counters differ: GPU %s oracle %s" % (g_cnt, o_cnt)
+    assert np.count_nonzero(want.sum(axis=1)) > 4000
+
+    # intermediate results, bit for bit
+    from test_gpu_parity import oracle_probe
+    sub = rays[::8][:600]
+    probes = rta.probe(gw, sub)
+    for g, w_, r in zip(probes, oracle_probe(orc, ow, sub), sub):
+        if w_ is None:
+            assert g["object"] == -1
+            continue
+        t, obj, c = w_
+        assert g["object"] == obj and g["t"] == t, "hit differs for ray %s" % (r,)
+        assert np.array_equal(g["point"], c.point[:]) and np.array_equal(g["normalv"], c.normalv[:])
+        assert np.array_equal(g["over_point"], c.over_point[:]) and np.array_equal(g["reflectv"], c.reflectv[:])
+        assert bool(g["shadowed"]) == orc.is_shadowed(ow, c.over_point[:])
+
+    # the frame itself: the sampled pixels are the colours of their rays, the counters add up
+    st = {}
+    img = rta.render_rows(gcam, gw, stats=st)
+    assert np.abs(img[ys, xs] - want[:3000]).max() <= TOL
+    assert st["rays_per_level"][0] == W * H and st["color_rays"] == sum(st["rays_per_level"])
+    assert st["rays_per_level"][1] > 0 and st["rays_per_level"][5] > 0
+    assert st["shadow_rays"] <= st["color_rays"]
+    # every camera ray ends on the floor, the wall or an object: every pixel is a shaded hit
+    assert st["shadow_rays"] >= W * H
+    band = rta.render_rows(gcam, gw, row_begin=1070, row_end=1100)
+    assert np.abs(band - img[1070:1100]).max() <= 1e-12
+
+
+def test_default_world_4k_on_the_f32_path(orc, rta):
+    """BASELINE config 2 in f32: after the reference's 8-bit conversion (src/scenes/canvas.rs:84-86)
+    at least 99.9 % of the pixels are within one level of the f64 oracle, on 40 000 sampled
+    pixels, half of them where the spheres are."""
+    from ray_tracer_amd import scenes
+    W, H = 3840, 2160
+    gw, gcam = scenes.default_scene(rta.api, W, H)
+    ow, ocam = scenes.default_scene(orc.api, W, H)
+    st = {}
+    img = rta.render_rows(gcam, gw, precision=rta.F32, stats=st)
+    assert st["color_rays"] == W * H
+    rng = np.random.default_rng(5)
+    n = 40000
+    xs, ys = rng.integers(0, W, n), rng.integers(0, H, n)
+    xs[: n // 2] = rng.integers(1500, 2340, n // 2)
+    ys[: n // 2] = rng.integers(1300, 2000, n // 2)
+    want = orc.color_at(ow, _camera_rays(orc, ocam, xs, ys))
+    q_got = orc.quantize_u8(img[ys, xs].astype(np.float64)).astype(np.int32)
+    q_want = orc.quantize_u8(want).astype(np.int32)
+    close = np.all(np.abs(q_got - q_want) <= 1, axis=1)
+    assert close.mean() >= 0.999, "only %.4f %% of the pixels within 1/255" % (100.0 * close.mean())
+    assert np.count_nonzero(want.sum(axis=1)) > 5000
+    # the frame's lit pixels are those of the f64 frame, give or take the silhouettes
+    img64 = rta.render_rows(gcam, gw)
+    differ = np.count_nonzero((img.sum(axis=2) > 0) != (img64.sum(axis=2) > 0))
+    assert differ <= 0.0005 * W * H
+
+
+def test_8k_multi_light_frame_from_eight_row_tiles(orc, rta):
+    """BASELINE config 5 up to the gather: the 7680x4320 glass frame with four lights in the World
+    (only lights[0] shades, src/scenes/world.rs:123,147), rendered once whole and once as the
+    eight row tiles of whole 10-row bands that eight ranks would render, into one buffer."""
+    from ray_tracer_amd import scenes, sharding
+    W, H = 7680, 4320
+    hip = hiprt.runtime()
+    gw, gcam = scenes.glass_scene(rta.api, W, H, n_lights=4)
+    ow, ocam = scenes.glass_scene(orc.api, W, H, n_lights=4)
+    flat = rta.flatten(gw)
+    assert flat["light_position"].size == 12
+    ctx = rta.Context()
+    scene = rta.Scene(ctx, flat)
+    cd = rta.camera_desc(gcam)
+    nbytes = W * H * 24
+    whole, tiled = hiprt.Buffer(hip, nbytes), hiprt.Buffer(hip, nbytes)
+    stream = hiprt.new_stream(hip)
+    try:
+        st = {}
+        rta.render_device(ctx, scene, cd, 5, rta.F64, 0, H, whole.ptr.value, nbytes, stream.value, st)
+        tiles = sharding.row_tiles(H, 8)
+        assert tiles[0][0] == 0 and tiles[-1][1] == H and all(a % 10 == 0 for a, _ in tiles)
+        tile_rays = 0
+        for r0, r1 in tiles:
+            ts = {}
+            rta.render_device(ctx, scene, cd, 5, rta.F64, r0, r1, tiled.ptr.value + r0 * W * 24, (r1 - r0) * W * 24, stream.value, ts)
+            tile_rays += ts["color_rays"] + ts["shadow_rays"]
+        assert tile_rays == st["color_rays"] + st["shadow_rays"]
+        a = whole.read((H, W, 3), np.float64, stream)
+        b = tiled.read((H, W, 3), np.float64, stream)
+        assert np.abs(a - b).max() <= 1e-12
+        rng = np.random.default_rng(8)
+        xs, ys = rng.integers(0, W, 1500), rng.integers(0, H, 1500)
+        want = orc.color_at(ow, _camera_rays(orc, ocam, xs, ys))
+        assert np.abs(a[ys, xs] - want).max() <= TOL
+        assert st["rays_per_level"][0] == W * H and st["rays_per_level"][5] > 0
+    finally:
+        hip.hipStreamDestroy(stream)
+        whole.free()
+        tiled.free()
+        scene.close()
+        ctx.close()
