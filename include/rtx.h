@@ -205,6 +205,25 @@ int rtx_render_device(rtx_context *ctx, const rtx_scene *scene, const rtx_camera
                       void *stream, rtx_stats *stats);
 
 /*
+ * One part of a frame that several GPUs render together, left in device memory.  The image's
+ * bands of band_rows rows (10 in the reference, src/scenes/camera.rs:177) are dealt out in turn:
+ * band b belongs to part b mod n_parts, so that every part gets its share of the cheap rows (sky)
+ * and of the dear ones (glass) -- contiguous tiles do not.  The call renders the bands of `part`
+ * into d_out back to back: rtx_part_rows() rows of hsize pixels, local row L being image row
+ * ((L / band_rows) * n_parts + part) * band_rows + L % band_rows.  n_parts = 1 is the whole frame.
+ * format 0: three values per pixel (double or float, as rtx_render_device); an RTX_PIXELS_* value:
+ * 8-bit pixels converted on the device as in rtx_render_8bit -- by the kernel that shades the
+ * pixel when the frame has no secondary rays (no frame of values ever exists), by one more pass
+ * over the part otherwise.  A sixth (RGBA8) or an eighth (RGB8) of the bytes of f64 values then
+ * has to travel to the GPU that assembles the frame.  `stream` and `stats` as rtx_render_device.
+ * Stands in for the loop over bands of Camera::parallel_render (camera.rs:181-193).
+ */
+uint32_t rtx_part_rows(uint32_t vsize, uint32_t band_rows, uint32_t n_parts, uint32_t part);
+int rtx_render_part_device(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_desc *camera, uint32_t max_depth,
+                           int precision, uint32_t band_rows, uint32_t n_parts, uint32_t part, uint32_t format, void *d_out,
+                           size_t out_bytes, void *stream, rtx_stats *stats);
+
+/*
  * rtx_render_device for callers that cannot allocate: code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  The call
  * allocates and frees nothing, on the device or through any library: the counters, the per-frame

@@ -127,6 +127,10 @@ rtx_render_8bit = _bind("rtx_render_8bit", C.c_int, [_vp, _vp, C.POINTER(CameraD
                                                      C.c_uint32, _vp, C.c_size_t, _vp, _vp, C.POINTER(Stats)])
 rtx_render_device = _bind("rtx_render_device", C.c_int, [_vp, _vp, C.POINTER(CameraDesc), C.c_uint32, C.c_int, C.c_uint32,
                                                          C.c_uint32, _vp, C.c_size_t, _vp, C.POINTER(Stats)])
+rtx_part_rows = _bind("rtx_part_rows", C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32])
+rtx_render_part_device = _bind("rtx_render_part_device", C.c_int, [_vp, _vp, C.POINTER(CameraDesc), C.c_uint32, C.c_int, C.c_uint32,
+                                                                   C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_size_t, _vp,
+                                                                   C.POINTER(Stats)])
 rtx_render_device_noalloc = _bind("rtx_render_device_noalloc", C.c_int, [_vp, _vp, C.POINTER(CameraDesc), C.c_uint32, C.c_int,
                                                                          C.c_uint32, C.c_uint32, _vp, C.c_size_t, _vp])
 rtx_trace_rays = _bind("rtx_trace_rays", C.c_int, [_vp, _vp, _dp, C.c_size_t, C.c_uint32, C.c_int, _dp, C.POINTER(Stats)])
@@ -140,7 +144,7 @@ rtx_device_info = _bind("rtx_device_info", C.c_int, [_vp, C.c_char_p, C.c_size_t
 RTX_SYMBOLS = ["rtx_last_error", "rtx_context_create", "rtx_context_destroy", "rtx_context_synchronize",
                "rtx_context_set_debug_queue_divisor", "rtx_context_set_workspace_limit",
                "rtx_context_set_cull_threshold",
-               "rtx_scene_upload", "rtx_scene_destroy", "rtx_scene_features", "rtx_render", "rtx_render_8bit", "rtx_render_device", "rtx_render_device_noalloc", "rtx_trace_rays",
+               "rtx_scene_upload", "rtx_scene_destroy", "rtx_scene_features", "rtx_render", "rtx_render_8bit", "rtx_render_device", "rtx_part_rows", "rtx_render_part_device", "rtx_render_device_noalloc", "rtx_trace_rays",
                "rtx_probe_rays", "rtx_selfcheck_division", "rtx_generate_rays", "rtx_quantize_u8_device", "rtx_device_info"]
 
 
@@ -363,6 +367,15 @@ def camera_desc(camera):
         d.inverse_transform[i] = v
     d.pixel_size, d.half_width, d.half_height = g["pixel_size"], g["half_width"], g["half_height"]
     return d
+
+
+def render_part_device(ctx, scene, cam_desc, depth, precision, band_rows, n_parts, part, fmt, d_ptr, nbytes, stream=None, stats=None):
+    """rtx_render_part_device: the bands of one part of the frame, values (fmt 0) or 8-bit pixels, in device memory."""
+    st = Stats() if stats is not None else None
+    _check(rtx_render_part_device(ctx.h, scene.h, C.byref(cam_desc), depth, precision, band_rows, n_parts, part, fmt, _vp(d_ptr),
+                                  nbytes, _vp(stream) if stream else None, C.byref(st) if st is not None else None))
+    if stats is not None:
+        stats.update(st.as_dict())
 
 
 def render_device(ctx, scene, cam_desc, depth, precision, row_begin, row_end, d_ptr, nbytes, stream=None, stats=None):

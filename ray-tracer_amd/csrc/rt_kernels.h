@@ -90,11 +90,39 @@ RT_DEV void count_hits(StatShard *__restrict__ stats, uint32_t group, uint32_t l
     }
 }
 
+// Canvas::canvas_to_png / canvas_to_buffer (src/scenes/canvas.rs:80-104): three channels
+// `(c * 255.999) as u8`, and with four bytes per pixel an alpha byte of 255.
+// Canvas::canvas_to_ppm (canvas.rs:52-71) scales by 255.0 instead, casts to isize and clamps to
+// 0..255.  Both casts truncate toward zero, saturate and send NaN to 0, so one routine serves.
+template <typename R> RT_DEV uint32_t to_u8(R c, R scale)
+{
+    const R v = c * scale;
+    if (!(v == v) || v <= R(0)) return 0u;
+    if (v >= R(255)) return 255u;
+    return (uint32_t)(int)v;
+}
+// Pixel p of an 8-bit image in `format` (an RTX_PIXELS_* value: bytes per pixel in the low byte,
+// conversion rule above it).
+template <typename R> RT_DEV void store_pixel8(uint8_t *__restrict__ out, uint32_t p, uint32_t format, R cr, R cg, R cb)
+{
+    const R scale = (format >> 8) ? R(255.0) : R(255.999);
+    const uint32_t r = to_u8(cr, scale), g = to_u8(cg, scale), b = to_u8(cb, scale);
+    if ((format & 0xffu) == 4u) {
+        reinterpret_cast<uint32_t *>(out)[p] = r | (g << 8) | (b << 16) | (255u << 24);
+    } else {
+        uint8_t *o = out + (size_t)p * 3;
+        o[0] = (uint8_t)r; o[1] = (uint8_t)g; o[2] = (uint8_t)b;
+    }
+}
+
 // The work of one primary ray once it exists: trace, store the pixel's own lighting term,
-// queue the children.
-template <typename R, uint32_t SF, bool CAM>
+// queue the children.  format 0: fb holds 3 values of R per pixel; otherwise it is an 8-bit
+// image in that format and the term is converted as it is stored (only frames whose pixels
+// receive nothing from deeper levels are rendered that way).
+template <typename R, uint32_t SF, bool CAM, bool OUT8 = false>
 RT_DEV void primary_ray(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> ro, V3<R> rd, uint32_t k, bool valid,
-                        uint32_t remaining, R *__restrict__ fb, const QueueDev<R> &out_q, StatShard *__restrict__ stats)
+                        uint32_t remaining, void *__restrict__ fb, uint32_t format, const QueueDev<R> &out_q,
+                        StatShard *__restrict__ stats)
 {
     Node<R> nd;
     nd.hit = false;
@@ -107,15 +135,20 @@ RT_DEV void primary_ray(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> ro, V
                 queue_push2(out_q, sub, c.has_reflect, c.over_point, c.reflectv, c.reflect_factor, c.has_refract, c.under_point,
                             c.refract_dir, c.refract_factor, k);
         });
-        R *px = fb + (size_t)k * 3;
-        px[0] = nd.lighting.x;
-        px[1] = nd.lighting.y;
-        px[2] = nd.lighting.z;
+        if constexpr (!OUT8) {
+            R *px = static_cast<R *>(fb) + (size_t)k * 3;
+            px[0] = nd.lighting.x;
+            px[1] = nd.lighting.y;
+            px[2] = nd.lighting.z;
+        } else {
+            store_pixel8<R>(static_cast<uint8_t *>(fb), k, format, nd.lighting.x, nd.lighting.y, nd.lighting.z);
+        }
     }
     count_hits(stats, blockIdx.x, 0, valid && nd.hit);
 }
 
-// Camera rays of rows [row0, row0 + n_rows), one pixel per lane.  Each wave takes one 64-pixel
+// Camera rays of local rows [local0, local0 + n_rows) of `map`, one pixel per lane; the output
+// pixel of local row L and column x is L * hsize + x, counted from fb.  Each wave takes one 64-pixel
 // segment of a row, so its framebuffer stores cover one contiguous run; with bounding-sphere
 // tests it takes an 8x8 tile instead (camera_blocks() in rt_launch.h).  There is no loop: the
 // camera block is dead once the ray exists, which leaves the scalar register file to the
@@ -123,10 +156,11 @@ RT_DEV void primary_ray(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> ro, V
 #ifndef RTX_CAMERA_ATTR
 #define RTX_CAMERA_ATTR
 #endif
-template <typename R, uint32_t SF>
+template <typename R, uint32_t SF, bool OUT8 = false, bool BANDED = false>
 __global__ void __launch_bounds__(kCamBlock) RTX_CAMERA_ATTR
-k_primary_camera(CameraDev<R> cam, SceneDev<R> S, PrimScene<R> P, uint32_t row0, uint32_t n_rows, uint32_t pieces_per_row,
-                 uint32_t remaining, R *__restrict__ fb, QueueDev<R> out_q, StatShard *__restrict__ stats)
+k_primary_camera(CameraDev<R> cam, SceneDev<R> S, PrimScene<R> P, uint32_t local0, uint32_t n_rows, uint32_t pieces_per_row,
+                 uint32_t remaining, void *__restrict__ fb, QueueDev<R> out_q, StatShard *__restrict__ stats, RowMap map,
+                 uint32_t format)
 {
 #ifdef RTX_LDS_TABLES
     if constexpr ((SF & SF_CULL) == 0) stage_tables<R>(S);
@@ -145,8 +179,14 @@ k_primary_camera(CameraDev<R> cam, SceneDev<R> S, PrimScene<R> P, uint32_t row0,
     const bool valid = row < n_rows && x < cam.hsize;
     V3<R> ro = { R(0), R(0), R(0) }, rd = ro;
     RTX_PHASE_INIT();
-    if (valid) ray_for_pixel(cam, x, row0 + row, ro, rd);
-    primary_ray<R, SF, true>(S, P, ro, rd, row * cam.hsize + x, valid, remaining, fb, out_q, stats);
+    if (valid) {
+        // plain row ranges come with local0 = their first image row and never read the map
+        uint32_t image_row = local0 + row;
+        if constexpr (BANDED)
+            image_row = map.first + ((image_row / map.band) * map.n_parts + map.part) * map.band + image_row % map.band;
+        ray_for_pixel(cam, x, image_row, ro, rd);
+    }
+    primary_ray<R, SF, true, OUT8>(S, P, ro, rd, row * cam.hsize + x, valid, remaining, fb, format, out_q, stats);
     RTX_PHASE_FLUSH();
 }
 
@@ -168,7 +208,7 @@ k_primary_rays(SceneDev<R> S, const double *__restrict__ rays, uint32_t n, uint3
         ro = { R(r[0]), R(r[1]), R(r[2]) };
         rd = { R(r[3]), R(r[4]), R(r[5]) };
     }
-    primary_ray<R, SF, false>(S, none, ro, rd, k, valid, remaining, fb, out_q, stats);
+    primary_ray<R, SF, false>(S, none, ro, rd, k, valid, remaining, fb, 0u, out_q, stats);
 }
 
 // First kernel of a frame: zero the queue counters and the hit counters, and let one thread
@@ -219,32 +259,15 @@ __global__ void __launch_bounds__(kBlock) k_quantize(const R *__restrict__ rgb, 
     }
 }
 
-// Canvas::canvas_to_png / canvas_to_buffer (src/scenes/canvas.rs:80-104): one pixel per thread,
-// three channels `(c * 255.999) as u8`, and with four bytes per pixel an alpha byte of 255.
-// Canvas::canvas_to_ppm (canvas.rs:52-71) scales by 255.0 instead, casts to isize and clamps to
-// 0..255.  Both casts truncate toward zero, saturate and send NaN to 0, so one routine serves.
-template <typename R> RT_DEV uint32_t to_u8(R c, R scale)
-{
-    const R v = c * scale;
-    if (!(v == v) || v <= R(0)) return 0u;
-    if (v >= R(255)) return 255u;
-    return (uint32_t)(int)v;
-}
+// One pixel per thread of an R-valued image into an 8-bit one (store_pixel8).
 template <typename R>
 __global__ void __launch_bounds__(kBlock)
 k_pack8(const R *__restrict__ rgb, uint32_t n_pix, uint32_t format, uint8_t *__restrict__ out)
 {
     const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= n_pix) return;
-    const R scale = (format >> 8) ? R(255.0) : R(255.999);
     const R *c = rgb + (size_t)p * 3;
-    const uint32_t r = to_u8(c[0], scale), g = to_u8(c[1], scale), b = to_u8(c[2], scale);
-    if ((format & 0xffu) == 4u) {
-        reinterpret_cast<uint32_t *>(out)[p] = r | (g << 8) | (b << 16) | (255u << 24);
-    } else {
-        uint8_t *o = out + (size_t)p * 3;
-        o[0] = (uint8_t)r; o[1] = (uint8_t)g; o[2] = (uint8_t)b;
-    }
+    store_pixel8<R>(out, p, format, c[0], c[1], c[2]);
 }
 
 // ---- launchers --------------------------------------------------------------------------
@@ -300,16 +323,29 @@ template <typename R> inline uint32_t table_lds_bytes(const SceneDev<R> &S)
 }
 template <typename R>
 hipError_t Launch<R>::primary_camera(uint32_t sf, hipStream_t stream, const CameraDev<R> &cam, const SceneDev<R> &scene,
-                                     const PrimScene<R> &prim, uint32_t row0, uint32_t n_rows, uint32_t remaining, R *fb,
-                                     const QueueDev<R> &out_q, StatShard *stats)
+                                     const PrimScene<R> &prim, const RowMap &map, uint32_t local0, uint32_t n_rows,
+                                     uint32_t remaining, void *fb, uint32_t format, const QueueDev<R> &out_q, StatShard *stats)
 {
-    const uint32_t pieces_per_row = camera_pieces_per_row(sf, cam.hsize);
     const uint32_t grid = (uint32_t)camera_blocks(sf, cam.hsize, n_rows);
-#define RTX_CALL(SFV)                                                                                               \
-    hipLaunchKernelGGL((k_primary_camera<R, SFV | SF_PATTERN>), dim3(grid), dim3(kCamBlock), table_lds_bytes(scene), stream, cam, scene, prim, \
-                       row0, n_rows, pieces_per_row, remaining, fb, out_q, stats)
+    const uint32_t pieces_per_row = camera_pieces_per_row(sf, cam.hsize);
+    // the 8-bit variants exist for the scenes that can use them: those in which nothing reflects or
+    // refracts; the variants that deal bands out to parts spare the plain row range their divisions
+    const bool banded = map.n_parts != 1u;
+    const uint32_t first = banded ? local0 : map.first + local0;  // what the kernel adds its row to
+#define RTX_LAUNCH_CAM(SFV, OUT8, BANDED)                                                                            \
+    hipLaunchKernelGGL((k_primary_camera<R, SFV | SF_PATTERN, OUT8, BANDED>), dim3(grid), dim3(kCamBlock), table_lds_bytes(scene), \
+                       stream, cam, scene, prim, first, n_rows, pieces_per_row, remaining, fb, out_q, stats, map, format)
+#define RTX_CALL(SFV)                                                                                                \
+    if constexpr (((SFV) & (SF_REFLECTIVE | SF_TRANSPARENT)) == 0) {                                               \
+        if (format != 0u) { if (banded) RTX_LAUNCH_CAM(SFV, true, true); else RTX_LAUNCH_CAM(SFV, true, false); }    \
+        else { if (banded) RTX_LAUNCH_CAM(SFV, false, true); else RTX_LAUNCH_CAM(SFV, false, false); }               \
+    } else {                                                                                                         \
+        if (format != 0u) return hipErrorInvalidValue;                                                               \
+        if (banded) RTX_LAUNCH_CAM(SFV, false, true); else RTX_LAUNCH_CAM(SFV, false, false);                        \
+    }
     RTX_SF_SWITCH(sf, RTX_CALL)
 #undef RTX_CALL
+#undef RTX_LAUNCH_CAM
     return hipGetLastError();
 }
 

@@ -44,11 +44,12 @@ inline uint64_t camera_blocks(uint32_t sf, uint32_t hsize, uint64_t n_rows)
 
 template <typename R>
 struct Launch {
-    // Camera rays of rows [row0, row0 + n_rows): intersect, shade, store the lighting term at
-    // fb[3 * (row * hsize + x)] (row relative to row0), queue the children.
+    // Camera rays of local rows [local0, local0 + n_rows) of `map`: intersect, shade, store the
+    // lighting term of pixel (row, x) at pixel index row * hsize + x of fb (row relative to local0;
+    // format 0: three values of R per pixel, otherwise an 8-bit RTX_PIXELS_* image), queue the children.
     static hipError_t primary_camera(uint32_t sf, hipStream_t stream, const CameraDev<R> &cam, const SceneDev<R> &scene,
-                                     const PrimScene<R> &prim, uint32_t row0, uint32_t n_rows, uint32_t remaining, R *fb,
-                                     const QueueDev<R> &out_q, StatShard *stats);
+                                     const PrimScene<R> &prim, const RowMap &map, uint32_t local0, uint32_t n_rows,
+                                     uint32_t remaining, void *fb, uint32_t format, const QueueDev<R> &out_q, StatShard *stats);
     // The same for rays[0..n) supplied by the caller (6 doubles each), result at fb[3 * k].
     static hipError_t primary_rays(uint32_t sf, hipStream_t stream, const SceneDev<R> &scene, const double *rays,
                                    uint32_t n, uint32_t remaining, R *fb, const QueueDev<R> &out_q, StatShard *stats);

@@ -173,6 +173,15 @@ struct CameraDev {
     double inv_hsize;
 };
 
+// Which image rows a render call covers, in the order its output buffer holds them ("local"
+// rows).  A call covers the bands of `band` rows that fall to part `part` of `n_parts` when bands
+// are dealt out in turn (band b goes to part b mod n_parts), starting at image row `first`:
+// local row L is image row first + ((L / band) * n_parts + part) * band + L % band.  A plain row
+// range is the case n_parts = 1.
+struct RowMap {
+    uint32_t first, band, n_parts, part;
+};
+
 // Secondary-ray queue: 8 scalars per entry (origin, direction, path weight, pixel index).
 // A queue is split into n_sub sub-queues of cap_sub entries, each with its own length counter:
 // appends to ONE counter from every wave of the chip serialise (about 11 ns each on MI355X),

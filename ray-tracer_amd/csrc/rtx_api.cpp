@@ -759,18 +759,20 @@ int check_overflow(rtx_context *ctx)
     return RTX_OK;
 }
 
-// Enqueue every kernel of one frame (or ray batch) on `stream`.  Camera renders cover n_units rows
-// starting at row first_row; batches cover n_units rays of d_rays.  `ev` (four events) is only
-// used when timed.
+// Enqueue every kernel of one frame (or ray batch) on `stream`.  Camera renders cover the first
+// n_units local rows of `map`; batches cover n_units rays of d_rays.  format 0: d_fb holds three
+// values of R per pixel; otherwise it is an 8-bit image written by the primary kernel itself,
+// which only a frame without secondary rays can be.  `ev` (four events) is only used when timed.
 template <typename R>
 int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Workspace &ws, hipEvent_t *ev, hipStream_t stream,
-                  const CameraDev<R> *cam, const double *d_rays, uint32_t first_row, uint64_t n_units, uint32_t max_depth, R *d_fb,
-                  rtx_progress_fn progress, void *user, bool timed, uint32_t *n_chunks_out, uint32_t *n_launch_out)
+                  const CameraDev<R> *cam, const double *d_rays, const RowMap &map, uint64_t n_units, uint32_t max_depth, void *d_fb,
+                  uint32_t format, rtx_progress_fn progress, void *user, bool timed, uint32_t *n_chunks_out, uint32_t *n_launch_out)
 {
     FramePlan plan;
     const uint32_t W = cam ? cam->hsize : 0;
     int rc = plan_frame<R>(ws.fixed ? ws.queue_bytes : ctx->workspace_limit, scene->sf, max_depth, W, n_units, &plan);
     if (rc) return rc;
+    if (format != 0u && plan.levels != 0u) return fail(RTX_ERR_INVALID, "internal: 8-bit output straight from a frame with secondary rays");
     if (ctx->debug_queue_divisor > 1)
         for (auto &c : plan.cap_sub) c = c ? std::max<uint64_t>(1, c / ctx->debug_queue_divisor) : 0;
     const uint32_t n_chunks = (uint32_t)((n_units + plan.chunk_units - 1) / plan.chunk_units);
@@ -861,11 +863,12 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Workspace &ws, hipEv
             return q;
         };
         const uint64_t k0 = cam ? u0 * W : u0;  // first primary ray of the chunk
-        R *fb = d_fb + k0 * 3;
+        char *fb_bytes = (char *)d_fb + k0 * (format ? (size_t)(format & 0xffu) : 3 * sizeof(R));
+        R *fb = (R *)fb_bytes;
         if (timed && c == 0) HIP_TRY(hipEventRecord(ev[2], stream));
         if (cam) {
-            HIP_TRY(Launch<R>::primary_camera(scene->sf, stream, *cam, S, prim, first_row + (uint32_t)u0, (uint32_t)units,
-                                              max_depth, fb, queue_at(1), ws.shards));
+            HIP_TRY(Launch<R>::primary_camera(scene->sf, stream, *cam, S, prim, map, (uint32_t)u0, (uint32_t)units, max_depth,
+                                              fb_bytes, format, queue_at(1), ws.shards));
         } else {
             HIP_TRY(Launch<R>::primary_rays(scene->sf, stream, S, d_rays + k0 * 6, (uint32_t)units, max_depth, fb, queue_at(1),
                                             ws.shards));
@@ -938,12 +941,33 @@ int check_camera(const rtx_camera_desc *cam, uint32_t row_begin, uint32_t row_en
     return RTX_OK;
 }
 
-template <typename R>
-int render_impl(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_desc *cam, uint32_t max_depth,
-                uint32_t row_begin, uint32_t row_end, void *host_out, void *dev_out, hipStream_t user_stream,
-                rtx_progress_fn progress, void *user, rtx_stats *stats, uint32_t channels8 = 0)
+// Local rows of part `part` when the bands of `band` rows of a vsize-row image are dealt out in turn
+// to n_parts parts.
+uint32_t part_rows(uint32_t vsize, uint32_t band, uint32_t n_parts, uint32_t part)
 {
-    // channels8 != 0: an RTX_PIXELS_* format; host_out receives 8-bit pixels instead of R values
+    const uint64_t n_bands = ((uint64_t)vsize + band - 1) / band;
+    if (part >= n_bands) return 0;
+    const uint64_t mine = (n_bands - part + n_parts - 1) / n_parts;        // bands part, part + n_parts, ...
+    const uint64_t last = part + (mine - 1) * n_parts;                      // the last of them
+    const uint64_t last_rows = std::min<uint64_t>(band, vsize - last * band);
+    return (uint32_t)((mine - 1) * band + last_rows);
+}
+
+bool valid_format8(uint32_t format) { return format == RTX_PIXELS_RGB8 || format == RTX_PIXELS_RGBA8 || format == RTX_PIXELS_PPM8; }
+
+// The rows one call covers: a plain range [row_begin, row_end) or the bands of one part.
+struct Rows {
+    RowMap map;
+    uint32_t n_local;
+};
+Rows row_range(uint32_t row_begin, uint32_t row_end) { return { { row_begin, 1u, 1u, 0u }, row_end - row_begin }; }
+
+template <typename R>
+int render_impl(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_desc *cam, uint32_t max_depth, const Rows &rows,
+                void *host_out, void *dev_out, hipStream_t user_stream, rtx_progress_fn progress, void *user, rtx_stats *stats,
+                uint32_t channels8 = 0)
+{
+    // channels8 != 0: an RTX_PIXELS_* format; the output (host or device) receives 8-bit pixels instead of R values
     const auto t0 = std::chrono::steady_clock::now();
     int rc = check_overflow(ctx);
     if (rc) return rc;
@@ -954,14 +978,28 @@ int render_impl(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_desc 
     if (rc) return rc;
     Slot *slot = lease.slot;
     const uint64_t W = cam->hsize;
-    const uint64_t n_pix = (uint64_t)(row_end - row_begin) * W;
+    const uint64_t n_pix = (uint64_t)rows.n_local * W;
     if (stats) std::memset(stats, 0, sizeof *stats);
     if (n_pix == 0) return RTX_OK;
     hipStream_t stream = user_stream ? user_stream : slot->stream;
     rc = slot_order_after_pending(slot, stream);
     if (rc) return rc;
-    R *d_fb = (R *)dev_out;
-    if (!d_fb) {
+    // An 8-bit frame whose pixels get nothing from deeper levels is converted by the primary kernel
+    // as it stores (no R-valued frame exists at all); otherwise the levels accumulate in an R-valued
+    // frame and one more pass converts it.
+    const bool direct8 = channels8 != 0 && (scene->sf & (SF_REFLECTIVE | SF_TRANSPARENT)) == 0;
+    const size_t bytes8 = (size_t)(n_pix * (channels8 & 0xffu));
+    void *d_pixels8 = nullptr;  // where the 8-bit image goes on the device
+    if (channels8) {
+        d_pixels8 = dev_out;
+        if (!d_pixels8) {
+            rc = grow(&slot->aux, &slot->aux_bytes, bytes8);
+            if (rc) return rc;
+            d_pixels8 = slot->aux;
+        }
+    }
+    R *d_fb = channels8 ? nullptr : (R *)dev_out;
+    if (!d_fb && !direct8) {
         rc = grow(&slot->fb, &slot->fb_bytes, (size_t)(n_pix * 3 * sizeof(R)));
         if (rc) return rc;
         d_fb = (R *)slot->fb;
@@ -971,9 +1009,13 @@ int render_impl(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_desc 
     // without a stream of the caller's there is nothing the caller could wait on: the call waits itself
     const bool sync = host_out != nullptr || stats != nullptr || user_stream == nullptr;
     const bool timed = stats != nullptr;
-    rc = enqueue_frame<R>(ctx, scene, slot->ws, slot->ev, stream, &cd, nullptr, row_begin, row_end - row_begin, max_depth, d_fb,
-                          progress, user, timed, &n_chunks, &n_launch);
+    rc = enqueue_frame<R>(ctx, scene, slot->ws, slot->ev, stream, &cd, nullptr, rows.map, rows.n_local, max_depth,
+                          direct8 ? d_pixels8 : (void *)d_fb, direct8 ? channels8 : 0u, progress, user, timed, &n_chunks, &n_launch);
     if (rc) return rc;
+    if (channels8 && !direct8) {
+        HIP_TRY(Launch<R>::pack8(stream, d_fb, (uint32_t)n_pix, channels8, (uint8_t *)d_pixels8));
+        ++n_launch;
+    }
     if (!sync) {
         HIP_TRY(hipEventRecord(slot->done, stream));
         slot->pending = true;
@@ -981,11 +1023,7 @@ int render_impl(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_desc 
         return RTX_OK;
     }
     if (host_out && channels8) {
-        const size_t pixel_bytes = channels8 & 0xffu;
-        rc = grow(&slot->aux, &slot->aux_bytes, (size_t)(n_pix * pixel_bytes));
-        if (rc) return rc;
-        HIP_TRY(Launch<R>::pack8(stream, d_fb, (uint32_t)n_pix, channels8, (uint8_t *)slot->aux));
-        rc = copy_to_host(slot, stream, host_out, slot->aux, (size_t)(n_pix * pixel_bytes));
+        rc = copy_to_host(slot, stream, host_out, d_pixels8, bytes8);
         if (rc) return rc;
     } else if (host_out) {
         rc = copy_to_host(slot, stream, host_out, d_fb, (size_t)(n_pix * 3 * sizeof(R)));
@@ -1026,8 +1064,8 @@ int trace_impl(rtx_context *ctx, const rtx_scene *scene, const double *rays, siz
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(slot->aux, rays, ray_bytes, hipMemcpyHostToDevice, stream));
     uint32_t n_chunks = 0, n_launch = 0;
-    rc = enqueue_frame<R>(ctx, scene, slot->ws, slot->ev, stream, nullptr, (const double *)slot->aux, 0, n, max_depth, (R *)slot->fb,
-                          nullptr, nullptr, true, &n_chunks, &n_launch);
+    rc = enqueue_frame<R>(ctx, scene, slot->ws, slot->ev, stream, nullptr, (const double *)slot->aux, RowMap{ 0u, 1u, 1u, 0u }, n, max_depth,
+                          slot->fb, 0u, nullptr, nullptr, true, &n_chunks, &n_launch);
     if (rc) return rc;
     std::vector<R> tmp;
     void *dst = out_rgb;
@@ -1076,8 +1114,8 @@ int render_noalloc(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_de
     ws.queues = base + off;
     ws.queue_bytes = ctx->scratch_bytes - off;
     const CameraDev<R> cd = make_camera<R>(cam);
-    return enqueue_frame<R>(ctx, scene, ws, nullptr, stream, &cd, nullptr, row_begin, row_end - row_begin, max_depth, (R *)d_out,
-                            nullptr, nullptr, false, nullptr, nullptr);
+    return enqueue_frame<R>(ctx, scene, ws, nullptr, stream, &cd, nullptr, RowMap{ row_begin, 1u, 1u, 0u }, row_end - row_begin, max_depth,
+                            d_out, 0u, nullptr, nullptr, false, nullptr, nullptr);
 }
 
 }  // namespace
@@ -1305,8 +1343,8 @@ int rtx_render(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_desc *
     const size_t need = (size_t)(row_end - row_begin) * camera->hsize * 3 * elem;
     if (need && (!out_rgb || out_bytes < need)) return fail(RTX_ERR_INVALID, "output buffer holds %zu bytes, %zu needed", out_bytes, need);
     if (precision == RTX_F64)
-        return render_impl<double>(ctx, scene, camera, max_depth, row_begin, row_end, out_rgb, nullptr, nullptr, progress, user, stats);
-    return render_impl<float>(ctx, scene, camera, max_depth, row_begin, row_end, out_rgb, nullptr, nullptr, progress, user, stats);
+        return render_impl<double>(ctx, scene, camera, max_depth, row_range(row_begin, row_end), out_rgb, nullptr, nullptr, progress, user, stats);
+    return render_impl<float>(ctx, scene, camera, max_depth, row_range(row_begin, row_end), out_rgb, nullptr, nullptr, progress, user, stats);
 }
 
 int rtx_render_8bit(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_desc *camera, uint32_t max_depth, int precision,
@@ -1317,7 +1355,7 @@ int rtx_render_8bit(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_d
     int rc = check_camera(camera, row_begin, row_end);
     if (rc) return rc;
     if (precision != RTX_F64 && precision != RTX_F32) return fail(RTX_ERR_INVALID, "unknown precision %d", precision);
-    if (format != RTX_PIXELS_RGB8 && format != RTX_PIXELS_RGBA8 && format != RTX_PIXELS_PPM8)
+    if (!valid_format8(format))
         return fail(RTX_ERR_INVALID, "format must be RTX_PIXELS_RGB8 (3), RTX_PIXELS_RGBA8 (4) or RTX_PIXELS_PPM8 (0x103), not %u", format);
     const size_t need = (size_t)(row_end - row_begin) * camera->hsize * (format & 0xffu);
     if (need && (!out || out_bytes < need)) return fail(RTX_ERR_INVALID, "output buffer holds %zu bytes, %zu needed", out_bytes, need);
@@ -1326,9 +1364,9 @@ int rtx_render_8bit(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_d
         return RTX_OK;
     }
     if (precision == RTX_F64)
-        return render_impl<double>(ctx, scene, camera, max_depth, row_begin, row_end, out, nullptr, nullptr, progress, user, stats,
-                                   format);
-    return render_impl<float>(ctx, scene, camera, max_depth, row_begin, row_end, out, nullptr, nullptr, progress, user, stats,
+        return render_impl<double>(ctx, scene, camera, max_depth, row_range(row_begin, row_end), out, nullptr, nullptr, progress, user,
+                                   stats, format);
+    return render_impl<float>(ctx, scene, camera, max_depth, row_range(row_begin, row_end), out, nullptr, nullptr, progress, user, stats,
                               format);
 }
 
@@ -1344,8 +1382,41 @@ int rtx_render_device(rtx_context *ctx, const rtx_scene *scene, const rtx_camera
     const size_t need = (size_t)(row_end - row_begin) * camera->hsize * 3 * elem;
     if (need && (!d_out_rgb || out_bytes < need)) return fail(RTX_ERR_INVALID, "output buffer holds %zu bytes, %zu needed", out_bytes, need);
     if (precision == RTX_F64)
-        return render_impl<double>(ctx, scene, camera, max_depth, row_begin, row_end, nullptr, d_out_rgb, (hipStream_t)stream, nullptr, nullptr, stats);
-    return render_impl<float>(ctx, scene, camera, max_depth, row_begin, row_end, nullptr, d_out_rgb, (hipStream_t)stream, nullptr, nullptr, stats);
+        return render_impl<double>(ctx, scene, camera, max_depth, row_range(row_begin, row_end), nullptr, d_out_rgb, (hipStream_t)stream,
+                                   nullptr, nullptr, stats);
+    return render_impl<float>(ctx, scene, camera, max_depth, row_range(row_begin, row_end), nullptr, d_out_rgb, (hipStream_t)stream, nullptr,
+                              nullptr, stats);
+}
+
+uint32_t rtx_part_rows(uint32_t vsize, uint32_t band_rows, uint32_t n_parts, uint32_t part)
+{
+    if (band_rows == 0 || n_parts == 0 || part >= n_parts) return 0;
+    return part_rows(vsize, band_rows, n_parts, part);
+}
+
+int rtx_render_part_device(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_desc *camera, uint32_t max_depth,
+                           int precision, uint32_t band_rows, uint32_t n_parts, uint32_t part, uint32_t format, void *d_out,
+                           size_t out_bytes, void *stream, rtx_stats *stats)
+{
+    if (!ctx || !scene || scene->ctx != ctx) return fail(RTX_ERR_INVALID, "scene does not belong to this context");
+    int rc = check_camera(camera, 0, camera ? camera->vsize : 0);
+    if (rc) return rc;
+    if (precision != RTX_F64 && precision != RTX_F32) return fail(RTX_ERR_INVALID, "unknown precision %d", precision);
+    if (band_rows == 0 || n_parts == 0 || part >= n_parts)
+        return fail(RTX_ERR_INVALID, "part %u of %u parts with bands of %u rows is not a part of the frame", part, n_parts, band_rows);
+    if (format != 0 && !valid_format8(format))
+        return fail(RTX_ERR_INVALID, "format must be 0 (values), RTX_PIXELS_RGB8 (3), RTX_PIXELS_RGBA8 (4) or RTX_PIXELS_PPM8 (0x103), not %u", format);
+    const Rows rows = { { 0u, band_rows, n_parts, part }, part_rows(camera->vsize, band_rows, n_parts, part) };
+    const size_t elem = precision == RTX_F64 ? sizeof(double) : sizeof(float);
+    const size_t need = (size_t)rows.n_local * camera->hsize * (format ? (size_t)(format & 0xffu) : 3 * elem);
+    if (need && (!d_out || out_bytes < need)) return fail(RTX_ERR_INVALID, "output buffer holds %zu bytes, %zu needed", out_bytes, need);
+    if (need == 0) {
+        if (stats) std::memset(stats, 0, sizeof *stats);
+        return RTX_OK;
+    }
+    if (precision == RTX_F64)
+        return render_impl<double>(ctx, scene, camera, max_depth, rows, nullptr, d_out, (hipStream_t)stream, nullptr, nullptr, stats, format);
+    return render_impl<float>(ctx, scene, camera, max_depth, rows, nullptr, d_out, (hipStream_t)stream, nullptr, nullptr, stats, format);
 }
 
 int rtx_render_device_noalloc(rtx_context *ctx, const rtx_scene *scene, const rtx_camera_desc *camera, uint32_t max_depth,
