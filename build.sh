@@ -25,11 +25,12 @@ if [[ "$what" == "lib" || "$what" == "all" ]]; then
   "$HIPCC" --offload-arch=gfx950 $COMMON $LICM ${RTX_HIP_FLAGS:-} -ffp-contract=fast -fno-slp-vectorize -c "$PKG/csrc/bounce_f32.hip" -o "$PKG/build/bounce_f32.o" &
   "$HIPCC" --offload-arch=gfx950 $COMMON -c "$PKG/csrc/scratch.hip" -o "$PKG/build/scratch.o" &
   g++ $COMMON -ffp-contract=off -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -c "$PKG/csrc/rtx_api.cpp" -o "$PKG/build/rtx_api.o" &
+  g++ $COMMON -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -c "$PKG/csrc/rtx_multi.cpp" -o "$PKG/build/rtx_multi.o" &
   g++ $COMMON -ffp-contract=off -fno-fast-math -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -c "$PKG/host/rt.cpp" -o "$PKG/build/rt.o" &
   g++ $COMMON -ffp-contract=off -fno-fast-math -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -c "$PKG/host/rt_capi.cpp" -o "$PKG/build/rt_capi.o" &
   for job in $(jobs -p); do wait "$job" || { echo "error: a compile step failed"; exit 1; }; done
   "$HIPCC" --offload-arch=gfx950 -shared -fPIC -pthread -o "$OUT/$LIBNAME" "$PKG/build/render_f64.o" "$PKG/build/render_f32.o" "$PKG/build/bounce_f64.o" "$PKG/build/bounce_f32.o" "$PKG/build/scratch.o" \
-      "$PKG/build/rtx_api.o" "$PKG/build/rt.o" "$PKG/build/rt_capi.o"
+      "$PKG/build/rtx_api.o" "$PKG/build/rtx_multi.o" "$PKG/build/rt.o" "$PKG/build/rt_capi.o"
   echo "built $OUT/$LIBNAME"
 fi
 if [[ "$what" == "oracle" || "$what" == "all" ]]; then

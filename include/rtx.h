@@ -289,6 +289,41 @@ int rtx_generate_rays(rtx_context *ctx, const rtx_camera_desc *camera, uint64_t 
 int rtx_quantize_u8_device(rtx_context *ctx, const void *d_rgb, int precision, size_t n_values, uint8_t *d_out,
                            void *stream);
 
+/*
+ * One frame on several GPUs of a node, from one process: what the Rayon loop over bands of 10 rows
+ * of Camera::parallel_render (src/scenes/camera.rs:177-193) becomes on an 8-GPU node.  The World is
+ * uploaded to every GPU; band b of the image is rendered by GPU b mod n (no traffic while they
+ * render); every GPU then writes its bands to their places in the frame held by the first GPU
+ * (device_ids[0]) with one strided device-to-device copy over xGMI.  The frame is left there
+ * (out_on_first_device != 0: `out` is memory of that GPU) or copied on to host memory.
+ * format: 0 = values (double or float, 3 per pixel) or an RTX_PIXELS_* value; 8-bit pixels are
+ * converted on the GPU that renders them, so a sixth (RGBA8) of the bytes travel.
+ * The same device may be named more than once (a way to rehearse the path on fewer GPUs).
+ * Errors of these calls are reported by rtx_multi_last_error().
+ */
+typedef struct rtx_multi rtx_multi;
+typedef struct rtx_multi_scene rtx_multi_scene;
+typedef struct rtx_multi_stats {
+    uint64_t color_rays, shadow_rays;  /* filled only with RTX_MULTI_COUNT_RAYS */
+    double render_ms;     /* slowest GPU: its part, device time */
+    double gather_ms;     /* slowest GPU: its copy into the frame, device time */
+    double total_ms;      /* host wall time of the call */
+    uint64_t gather_bytes; /* bytes that left the GPUs other than the first */
+    uint32_t n_devices;
+    uint32_t pad;
+} rtx_multi_stats;
+/* count rays (makes every GPU's call wait for its kernels in turn: for reports, not for timing) */
+#define RTX_MULTI_COUNT_RAYS 1u
+const char *rtx_multi_last_error(void);
+int rtx_multi_create(const int *device_ids, int n_devices, rtx_multi **out);
+void rtx_multi_destroy(rtx_multi *multi);
+int rtx_multi_device_count(const rtx_multi *multi);
+int rtx_multi_scene_upload(rtx_multi *multi, const rtx_scene_desc *desc, rtx_multi_scene **out);
+void rtx_multi_scene_destroy(rtx_multi_scene *scene);
+int rtx_multi_render(rtx_multi *multi, const rtx_multi_scene *scene, const rtx_camera_desc *camera, uint32_t max_depth,
+                     int precision, uint32_t format, void *out, size_t out_bytes, int out_on_first_device, uint32_t flags,
+                     rtx_multi_stats *stats);
+
 /* Device properties the benchmark reports. */
 int rtx_device_info(rtx_context *ctx, char *name, size_t name_bytes, int *compute_units, int *clock_mhz);
 

@@ -138,6 +138,23 @@ rtx_probe_rays = _bind("rtx_probe_rays", C.c_int, [_vp, _vp, _dp, C.c_size_t, _v
 rtx_selfcheck_division = _bind("rtx_selfcheck_division", C.c_int, [_vp, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(C.c_uint64)])
 rtx_generate_rays = _bind("rtx_generate_rays", C.c_int, [_vp, C.POINTER(CameraDesc), C.c_uint64, C.c_size_t, _dp])
 rtx_quantize_u8_device = _bind("rtx_quantize_u8_device", C.c_int, [_vp, _vp, C.c_int, C.c_size_t, _vp, _vp])
+
+
+class MultiStats(C.Structure):
+    """rtx_multi_stats"""
+    _fields_ = [("color_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("render_ms", C.c_double), ("gather_ms", C.c_double),
+                ("total_ms", C.c_double), ("gather_bytes", C.c_uint64), ("n_devices", C.c_uint32), ("pad", C.c_uint32)]
+
+
+MULTI_COUNT_RAYS = 1
+rtx_multi_last_error = _bind("rtx_multi_last_error", C.c_char_p, [])
+rtx_multi_create = _bind("rtx_multi_create", C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_vp)])
+rtx_multi_destroy = _bind("rtx_multi_destroy", None, [_vp])
+rtx_multi_device_count = _bind("rtx_multi_device_count", C.c_int, [_vp])
+rtx_multi_scene_upload = _bind("rtx_multi_scene_upload", C.c_int, [_vp, C.POINTER(SceneDesc), C.POINTER(_vp)])
+rtx_multi_scene_destroy = _bind("rtx_multi_scene_destroy", None, [_vp])
+rtx_multi_render = _bind("rtx_multi_render", C.c_int, [_vp, _vp, C.POINTER(CameraDesc), C.c_uint32, C.c_int, C.c_uint32, _vp, C.c_size_t,
+                                                       C.c_int, C.c_uint32, C.POINTER(MultiStats)])
 rtx_device_info = _bind("rtx_device_info", C.c_int, [_vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)])
 
 # every symbol include/rtx.h declares
@@ -145,7 +162,8 @@ RTX_SYMBOLS = ["rtx_last_error", "rtx_context_create", "rtx_context_destroy", "r
                "rtx_context_set_debug_queue_divisor", "rtx_context_set_workspace_limit",
                "rtx_context_set_cull_threshold",
                "rtx_scene_upload", "rtx_scene_destroy", "rtx_scene_features", "rtx_render", "rtx_render_8bit", "rtx_render_device", "rtx_part_rows", "rtx_render_part_device", "rtx_render_device_noalloc", "rtx_trace_rays",
-               "rtx_probe_rays", "rtx_selfcheck_division", "rtx_generate_rays", "rtx_quantize_u8_device", "rtx_device_info"]
+               "rtx_probe_rays", "rtx_selfcheck_division", "rtx_generate_rays", "rtx_quantize_u8_device", "rtx_device_info", "rtx_multi_last_error", "rtx_multi_create",
+               "rtx_multi_destroy", "rtx_multi_device_count", "rtx_multi_scene_upload", "rtx_multi_scene_destroy", "rtx_multi_render"]
 
 
 class RtxError(RuntimeError):
@@ -306,6 +324,69 @@ def flatten(world):
         d.update(chain_depth=chain[:, 0].astype(np.uint8), chain_first=chain[:, 1].astype(np.uint32),
                  chain_inverse=flat(world, FLAT_CHAIN_INVERSE))
     return d
+
+
+def scene_desc(arrays):
+    """(rtx_scene_desc, the arrays it points into) from a dict of numpy arrays named after its fields."""
+    a = {k: (None if v is None else np.ascontiguousarray(v)) for k, v in arrays.items()}
+    n = int(a["shape_type"].size)
+    if a.get("pattern_color1") is None:
+        a["pattern_color1"] = np.tile(np.array([1.0, 1.0, 1.0]), n)
+    if a.get("pattern_color2") is None:
+        a["pattern_color2"] = np.zeros(3 * n)
+    d = SceneDesc()
+    d.n_objects = n
+    for name, ctype in SceneDesc._fields_:
+        if name in ("n_objects", "n_lights"):
+            continue
+        v = a.get(name)
+        if v is None:
+            setattr(d, name, None)
+            continue
+        want = {_dp: np.float64, _u8p: np.uint8, _u32p: np.uint32}[ctype]
+        v = np.ascontiguousarray(v, dtype=want)
+        a[name] = v
+        setattr(d, name, v.ctypes.data_as(ctype))
+    d.n_lights = int(a["light_position"].size // 3)
+    return d, a
+
+
+class MultiError(RuntimeError):
+    pass
+
+
+class Multi:
+    """Several GPUs rendering one frame (rtx_multi)."""
+
+    def __init__(self, device_ids):
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        h = _vp()
+        self._check(rtx_multi_create(ids, len(device_ids), C.byref(h)))
+        self.h = h
+        self.n = len(device_ids)
+
+    @staticmethod
+    def _check(status):
+        if status != 0:
+            raise MultiError(rtx_multi_last_error().decode("utf-8", "replace"))
+
+    def upload(self, arrays):
+        d, keep = scene_desc(arrays)
+        h = _vp()
+        self._check(rtx_multi_scene_upload(self.h, C.byref(d), C.byref(h)))
+        return h
+
+    def render(self, scene_h, cam_desc, depth, precision, fmt, out_ptr, nbytes, on_device=False, flags=0, stats=None):
+        st = MultiStats() if stats is not None else None
+        self._check(rtx_multi_render(self.h, scene_h, C.byref(cam_desc), depth, precision, fmt, _vp(out_ptr), nbytes,
+                                     1 if on_device else 0, flags, C.byref(st) if st is not None else None))
+        if stats is not None:
+            stats.update({k: getattr(st, k) for k, _ in MultiStats._fields_})
+
+    def close(self):
+        if self.h:
+            rtx_multi_destroy(self.h)
+            self.h = None
 
 
 class Scene:

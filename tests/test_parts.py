@@ -102,3 +102,50 @@ def test_8bit_frame_without_secondary_rays_is_one_launch(rta, orc):
         buf.free()
         scene.close()
         ctx.close()
+
+
+@pytest.mark.parametrize("scene_name,W,H,ids", [("default", 250, 197, [0, 0, 0]), ("glass", 320, 183, [0, 0]),
+                                                ("glass", 200, 95, [0] * 8)])
+def test_several_gpus_behind_the_c_abi(rta, orc, scene_name, W, H, ids):
+    """rtx_multi_*: the single-process path over n GPUs, rehearsed here with the one GPU of the box
+    named n times (n contexts, n scene uploads, n streams, bands dealt out in turn, strided copies
+    into the frame): values into host memory, RGBA8 into device memory."""
+    from ray_tracer_amd import scenes
+    hip = hiprt.runtime()
+    make = {"default": scenes.default_scene, "glass": scenes.glass_scene}[scene_name]
+    w, cam = make(rta.api, W, H)
+    flat = rta.flatten(w)
+    cd = rta.camera_desc(cam)
+    ctx = rta.Context()
+    scene = rta.Scene(ctx, flat)
+    whole = np.empty((H, W, 3))
+    st_whole = rta.Stats()
+    rta._check(rta.rtx_render(ctx.h, scene.h, cd, 5, rta.F64, 0, H, whole.ctypes.data, whole.nbytes, None, None, st_whole))
+    multi = rta.Multi(ids)
+    assert rta.rtx_multi_device_count(multi.h) == len(ids)
+    ms = multi.upload(flat)
+    buf = hiprt.Buffer(hip, W * H * 4)
+    try:
+        got = np.zeros((H, W, 3))
+        st = {}
+        multi.render(ms, cd, 5, rta.F64, 0, got.ctypes.data, got.nbytes, flags=rta.MULTI_COUNT_RAYS, stats=st)
+        assert np.abs(got - whole).max() <= 1e-12
+        assert st["color_rays"] + st["shadow_rays"] == st_whole.color_rays + st_whole.shadow_rays
+        assert st["n_devices"] == len(ids) and st["render_ms"] > 0
+        buf.fill(0x11)
+        st = {}
+        multi.render(ms, cd, 5, rta.F64, rta.PIXELS_RGBA8, buf.ptr.value, W * H * 4, on_device=True, stats=st)
+        rgba = buf.read((H, W, 4), np.uint8)
+        diff = np.abs(rgba[..., :3].astype(int) - orc.quantize_u8(whole).astype(int))
+        assert diff.max() <= (0 if scene_name == "default" else 1) and (diff != 0).mean() < 1e-3
+        assert (rgba[..., 3] == 255).all()
+        part0 = rta.rtx_part_rows(H, 10, len(ids), 0)
+        assert st["gather_bytes"] == (H - part0) * W * 4
+        with pytest.raises(rta.MultiError, match="too small"):
+            multi.render(ms, cd, 5, rta.F64, 0, got.ctypes.data, got.nbytes - 8)
+    finally:
+        buf.free()
+        rta.rtx_multi_scene_destroy(ms)
+        multi.close()
+        scene.close()
+        ctx.close()
