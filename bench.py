@@ -7,8 +7,9 @@ One step = one frame: every pixel's World::color_at at recursion depth 5, scene 
 resident in HBM, framebuffer left in HBM (rank 0's HBM after the gather when N > 1).  The
 headline workload is the reference's default world at 3840x2160 in f64.  With N > 1 (launched
 by torch.distributed.run, one rank per GPU) the frame is split into row tiles, each rank
-renders its tile and one RCCL gather assembles the frame on rank 0; the step time is the
-maximum over ranks.  Rank 0 prints one JSON line.
+renders the 10-row bands that fall to it (band b goes to rank b mod N, so every rank gets its
+share of cheap and of dear rows) and one RCCL gather assembles the frame on rank 0; the step
+time is the maximum over ranks.  Rank 0 prints one JSON line.
 """
 import argparse
 import json
@@ -54,6 +55,12 @@ def parse_args():
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary scenes reported under 'extra'")
     ap.add_argument("--cpu-seconds", type=float, default=20.0,
                     help="CPU work (seconds summed over threads) of the baseline sample")
+    ap.add_argument("--ramp-ms", type=float, default=300.0,
+                    help="untimed frames rendered before the warm-up steps until this much wall time has passed: the GPU "
+                         "needs a few milliseconds of load to leave its idle clocks, more than W short frames give it")
+    ap.add_argument("--gather", default="values", choices=["values", "rgba8"],
+                    help="what the ranks send to rank 0: the frame's values, or 8-bit RGBA pixels converted on the GPU that "
+                         "rendered them (src/scenes/canvas.rs:94-104), a sixth of the bytes in f64")
     return ap.parse_args()
 
 
@@ -135,15 +142,16 @@ def measured_traffic(scene_name, precision, width, height, kernel_prefix):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of
     this workload (profiles/), or None when there is no such profile.  FETCH_SIZE and WRITE_SIZE
     count KiB; FETCH_SIZE is doubled as gfx950 tallies 128-byte read requests at 64 bytes."""
-    path = os.path.join(ROOT, "profiles", "r01_%s_%dx%d_%s_pmc.json" % (scene_name, width, height, precision))
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
-        pmc = json.load(f)
-    for kernel, counters in pmc.items():
-        if kernel_prefix in kernel and "WRITE_SIZE" in counters and "FETCH_SIZE" in counters:
-            return (2.0 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024.0
-    return None
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", "%s_%s_%dx%d_%s_pmc.json" % (rnd, scene_name, width, height, precision))
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            pmc = json.load(f)
+        for kernel, counters in pmc.items():
+            if kernel_prefix in kernel and "WRITE_SIZE" in counters and "FETCH_SIZE" in counters:
+                return (2.0 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024.0, os.path.relpath(path, ROOT)
+    return None, None
 
 
 def main():
@@ -159,7 +167,11 @@ def main():
     distributed = world_size > 1 or os.environ.get("RTX_BENCH_DIST") == "1"
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
+        if "MASTER_PORT" not in os.environ:  # the single-rank rehearsal: any free port
+            import socket
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -174,24 +186,29 @@ def main():
     ctx = rta.Context(local_rank)
     scene = rta.Scene(ctx, flat)
     cd = rta.camera_desc(cam)
-    tiles = sharding.row_tiles(args.height, world_size)
-    r0, r1 = tiles[rank]
-    tile = torch.empty((r1 - r0, args.width, 3), dtype=tdtype, device="cuda")
+    W, H = args.width, args.height
+    # this rank's part: the bands b with b mod world_size == rank, back to back (the whole frame for one rank)
+    rows = sharding.part_rows(H, world_size, rank)
+    fmt = rta.PIXELS_RGBA8 if (distributed and args.gather == "rgba8") else 0
+    part = torch.empty((rows, W, 4), dtype=torch.uint8, device="cuda") if fmt else torch.empty((rows, W, 3), dtype=tdtype, device="cuda")
+    part_bytes = part.numel() * part.element_size()
     # One explicit HIP stream carries the render kernels, the timing events and (through
-    # torch's stream bookkeeping) the ordering against the RCCL gather.  A null handle would
-    # mean "the context's private stream" to rtx_render_device, which torch knows nothing about.
+    # torch's stream bookkeeping) the ordering against the RCCL gather.
     tstream = torch.cuda.Stream()
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
     assert stream != 0
+    frame = torch.empty((H, W) + tuple(part.shape[2:]), dtype=part.dtype, device="cuda") if distributed and rank == 0 else None
 
-    frame = torch.empty((args.height, args.width, 3), dtype=tdtype, device="cuda") if distributed and rank == 0 else None
+    def render(stats=None, desc=cd):
+        rta.render_part_device(ctx, scene, desc, args.depth, prec, sharding.BAND_SIZE, world_size, rank, fmt, part.data_ptr(),
+                               part_bytes, stream, stats)
 
     def step():
-        rta.render_device(ctx, scene, cd, args.depth, prec, r0, r1, tile.data_ptr(), tile.numel() * tile.element_size(), stream)
+        render()
         if distributed:
-            return sharding.gather_frame(tile, tiles, args.width, dst=0, out=frame)
-        return tile
+            return sharding.gather_parts(part, H, W, dst=0, out=frame)
+        return part
 
     def fence():
         torch.cuda.synchronize()
@@ -199,9 +216,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # ray counts of this rank's tile (deterministic per scene) and per-kernel device time
+    # ray counts of this rank's part (deterministic per scene) and per-kernel device time
     st = {}
-    rta.render_device(ctx, scene, cd, args.depth, prec, r0, r1, tile.data_ptr(), tile.numel() * tile.element_size(), stream, st)
+    render(st)
+    t_ramp = time.perf_counter()
+    while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
+        for _ in range(20):
+            render()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     fence()
@@ -215,13 +237,13 @@ def main():
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1) / args.steps
 
-    # the same loop without the gather: what the tiles alone cost (reported beside the step time, not as it)
+    # the same loop without the gather: what the parts alone cost (reported beside the step time, not as it)
     render_only_wall = None
     if distributed:
         fence()
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            rta.render_device(ctx, scene, cd, args.depth, prec, r0, r1, tile.data_ptr(), tile.numel() * tile.element_size(), stream)
+            render()
         fence()
         render_only_wall = time.perf_counter() - t1
 
@@ -229,21 +251,48 @@ def main():
     k_primary, k_all = [], []
     for _ in range(min(args.steps, 50)):
         s2 = {}
-        rta.render_device(ctx, scene, cd, args.depth, prec, r0, r1, tile.data_ptr(), tile.numel() * tile.element_size(), stream, s2)
+        render(s2)
         k_primary.append(s2["primary_kernel_ms"])
         k_all.append(s2["kernel_ms"])
-    # host-visible frame: render + copy to a host buffer (PCIe included), for the record
-    # (buffers zero-filled first, as Canvas::new does: the copy is not charged their page faults)
-    host = np.zeros((r1 - r0, args.width, 3), dtype=np.float64 if prec == rta.F64 else np.float32)
-    rgba = np.zeros((r1 - r0, args.width, 4), dtype=np.uint8)
-    host_ms = host_rgba8_ms = float("inf")
-    for _ in range(3):
-        t_h = time.perf_counter()
-        rta._check(rta.rtx_render(ctx.h, scene.h, cd, args.depth, prec, r0, r1, host.ctypes.data, host.nbytes, None, None, None))
-        host_ms = min(host_ms, (time.perf_counter() - t_h) * 1e3)
-        t_h = time.perf_counter()
-        rta._check(rta.rtx_render_8bit(ctx.h, scene.h, cd, args.depth, prec, r0, r1, 4, rgba.ctypes.data, rgba.nbytes, None, None, None))
-        host_rgba8_ms = min(host_rgba8_ms, (time.perf_counter() - t_h) * 1e3)
+
+    single = not distributed
+    moving_ms = host_ms = host_rgba8_ms = rgba8_ms = None
+    if single:
+        # A camera that moves between frames: a frame without secondary rays otherwise finds the
+        # per-camera tables of the previous frame still valid and skips the launch that fills them.
+        cams = [cd, moved_camera_desc(rta, cam)]
+        for k in range(10):
+            render(desc=cams[k & 1])
+        fence()
+        t_m = time.perf_counter()
+        for k in range(args.steps):
+            render(desc=cams[k & 1])
+        fence()
+        moving_ms = (time.perf_counter() - t_m) * 1e3 / args.steps
+        # the frame as 8-bit RGBA pixels left in device memory (what the reference's GUI displays)
+        rgba_dev = torch.empty((H, W, 4), dtype=torch.uint8, device="cuda")
+        for _ in range(5):
+            rta.render_part_device(ctx, scene, cd, args.depth, prec, sharding.BAND_SIZE, 1, 0, rta.PIXELS_RGBA8, rgba_dev.data_ptr(),
+                                   rgba_dev.numel(), stream)
+        fence()
+        t_r = time.perf_counter()
+        for _ in range(args.steps):
+            rta.render_part_device(ctx, scene, cd, args.depth, prec, sharding.BAND_SIZE, 1, 0, rta.PIXELS_RGBA8, rgba_dev.data_ptr(),
+                                   rgba_dev.numel(), stream)
+        fence()
+        rgba8_ms = (time.perf_counter() - t_r) * 1e3 / args.steps
+        # host-visible frame: render + copy to a host buffer (PCIe included), for the record
+        # (buffers zero-filled first, as Canvas::new does: the copy is not charged their page faults)
+        host = np.zeros((H, W, 3), dtype=np.float64 if prec == rta.F64 else np.float32)
+        rgba = np.zeros((H, W, 4), dtype=np.uint8)
+        host_ms = host_rgba8_ms = float("inf")
+        for _ in range(3):
+            t_h = time.perf_counter()
+            rta._check(rta.rtx_render(ctx.h, scene.h, cd, args.depth, prec, 0, H, host.ctypes.data, host.nbytes, None, None, None))
+            host_ms = min(host_ms, (time.perf_counter() - t_h) * 1e3)
+            t_h = time.perf_counter()
+            rta._check(rta.rtx_render_8bit(ctx.h, scene.h, cd, args.depth, prec, 0, H, 4, rgba.ctypes.data, rgba.nbytes, None, None, None))
+            host_rgba8_ms = min(host_rgba8_ms, (time.perf_counter() - t_h) * 1e3)
 
     vals = torch.tensor([wall, float(st["color_rays"]), float(st["shadow_rays"]), render_only_wall or 0.0], dtype=torch.float64,
                         device="cuda")
@@ -262,12 +311,16 @@ def main():
         ms_per_step = wall * 1e3 / args.steps
         rays = color_rays + shadow_rays
         value = rays / (ms_per_step * 1e-3) / 1e6
-        n_pix_tile = (r1 - r0) * args.width
-        flops_tile = algorithmic_flops(flat["shape_type"], n_pix_tile, st["color_rays"], st["shadow_rays"])
+        n_pix_part = rows * W
+        elem = 8 if prec == rta.F64 else 4
+        fb_bytes = n_pix_part * (4 if fmt else 3 * elem)
+        flops_part = algorithmic_flops(flat["shape_type"], n_pix_part, st["color_rays"], st["shadow_rays"])
         single_kernel = st["n_launches"] == 1
         k_ms = float(np.mean(k_primary)) if single_kernel else float(np.mean(k_all))
         peak = FP64_VECTOR_PEAK_TFLOPS if prec == rta.F64 else FP32_VECTOR_PEAK_TFLOPS
-        achieved = flops_tile / (k_ms * 1e-3) / 1e12
+        achieved = flops_part / (k_ms * 1e-3) / 1e12
+        traffic, traffic_source = (measured_traffic(args.scene, args.precision, W, H, "k_primary_camera")
+                                   if single_kernel and n_gpus == 1 else (None, None))
         out = {
             "metric": "Mrays/s (primary+secondary) at 4K depth-5; frame ms at 1/2/4/8 GPUs",
             "value": value,
@@ -282,12 +335,13 @@ def main():
             "dtype": args.precision,
             "data": "synthetic",
             "config": {
-                "workload": "%s scene %dx%d depth %d, %s" % (args.scene, args.width, args.height, args.depth, args.precision),
+                "workload": "%s scene %dx%d depth %d, %s" % (args.scene, W, H, args.depth, args.precision),
                 "objects": int(len(flat["shape_type"])),
                 "rays_per_frame": rays,
                 "color_rays": color_rays,
                 "shadow_rays": shadow_rays,
-                "parallelism": "row tiles x%d + 1 gather" % n_gpus if n_gpus > 1 else "single GPU",
+                "parallelism": ("10-row bands dealt out to %d ranks + 1 gather of %s" % (n_gpus, "RGBA8 pixels" if fmt else "values"))
+                if distributed else "single GPU",
             },
             "roofline": {
                 "bound": "valu",
@@ -296,41 +350,59 @@ def main():
                 "peak": peak,
                 "unit": "TFLOP/s",
                 "frac": achieved / peak,
-                "traffic": measured_traffic(args.scene, args.precision, args.width, args.height, "k_primary_camera")
-                if single_kernel and n_gpus == 1 else None,
+                # HBM bytes per launch from the committed counter passes of this workload (not collected in this run)
+                "traffic": traffic,
+                "traffic_source": traffic_source,
                 "kernel_ms": k_ms,
-                "algorithmic_flops_per_launch": flops_tile,
+                "algorithmic_flops_per_launch": flops_part,
                 "bounding_sphere_tests": scene.features()["bounding_sphere_tests"],
                 # with bounding-sphere tests most of the algorithm's ray/object tests are never executed:
                 # "achieved" then counts work that was skipped and "frac" says nothing about the ALUs
                 "frac_is_meaningful": not scene.features()["bounding_sphere_tests"],
-                "hbm_write_GBps": n_pix_tile * 3 * tile.element_size() / (k_ms * 1e-3) / 1e9,
                 # the same launch against the other roof: framebuffer bytes (the only HBM traffic) over the HBM peak
-                "hbm": {"achieved": n_pix_tile * 3 * tile.element_size() / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": n_pix_tile * 3 * tile.element_size() / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+                "hbm": {"achieved": fb_bytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": fb_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
             },
             "frame": {
+                "clock_ramp_ms_before_warmup": args.ramp_ms,
                 "device_ms_per_frame": dev_ms,
                 "color_only_Mrays_per_s": color_rays / (ms_per_step * 1e-3) / 1e6,
-                "host_copy_inclusive_ms": host_ms,
-                "host_rgba8_inclusive_ms": host_rgba8_ms,
                 "launches_per_frame": st["n_launches"],
             },
         }
+        if single:
+            out["frame"].update({
+                # every frame seen from another camera position: the per-camera tables are rebuilt each time
+                "moving_camera_ms": moving_ms,
+                "moving_camera_Mrays_per_s": rays / (moving_ms * 1e-3) / 1e6,
+                "rgba8_device_ms": rgba8_ms,
+                "host_copy_inclusive_ms": host_ms,
+                "host_rgba8_inclusive_ms": host_rgba8_ms,
+            })
         if distributed:
-            # slowest rank's tile without the gather, and the frame bytes the gather moves to rank 0
+            # slowest rank's part without the gather, and the bytes the gather moves to rank 0
             out["frame"]["render_only_ms"] = render_only_wall * 1e3 / args.steps
             out["frame"]["render_only_Mrays_per_s"] = rays / (render_only_wall / args.steps) / 1e6
-            out["frame"]["gather_bytes"] = args.height * args.width * 3 * tile.element_size() * (n_gpus - 1) // max(n_gpus, 1)
+            pixel_bytes = 4 if fmt else 3 * elem
+            out["frame"]["gather_bytes"] = (H - sharding.part_rows(H, world_size, 0)) * W * pixel_bytes
+            out["frame"]["gather_format"] = "rgba8" if fmt else args.precision
         if not args.no_cpu_baseline and n_gpus == 1:
-            out["cpu_baseline"] = cpu_baseline(args.scene, args.width, args.height, args.depth, args.objects, args.cpu_seconds)
-        if not args.no_extra and n_gpus == 1 and args.scene == "default" and args.precision == "f64":
+            out["cpu_baseline"] = cpu_baseline(args.scene, W, H, args.depth, args.objects, args.cpu_seconds)
+        if not args.no_extra and single and args.scene == "default" and args.precision == "f64":
             out["extra"] = extra_scenes(rta, ctx, args)
         print(json.dumps(out))
     scene.close()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def moved_camera_desc(rta, cam):
+    """The camera's rtx_camera_desc a quarter of a unit to the side (the fourth column of the
+    inverse view transform is the camera's position): another origin, so other per-camera tables."""
+    d = rta.camera_desc(cam)
+    d.inverse_transform[3] += 0.25
+    return d
 
 
 def extra_scenes(rta, ctx, args):
@@ -371,6 +443,12 @@ def extra_scenes(rta, ctx, args):
             "bounding_sphere_tests": culled,
         }
         scene.close()
+    if not args.no_cpu_baseline:
+        # the oracle beside the other two scenes as well (short samples: a few seconds of CPU work each)
+        for name in ("glass", "random"):
+            base = cpu_baseline(name, args.width, args.height, args.depth, 10000, min(args.cpu_seconds, 6.0))
+            res["%s_f64" % name]["cpu_baseline"] = base
+            res["%s_f64" % name]["gpu_over_cpu"] = res["%s_f64" % name]["Mrays_per_s"] / base["value"]
     return res
 
 

@@ -59,3 +59,58 @@ def gather_frame(local, tiles, hsize, dst=0, group=None, out=None):
         return frame
     dist.gather(send, gather_list=None, dst=dst, group=group)
     return None
+
+
+def part_image_rows(vsize, n_parts, part, band=BAND_SIZE):
+    """Image rows of one part when the bands are dealt out in turn (band b -> part b mod n_parts), in
+    the order rtx_render_part_device leaves them in its buffer."""
+    rows = []
+    for b in range(part, (vsize + band - 1) // band, n_parts):
+        rows.extend(range(b * band, min((b + 1) * band, vsize)))
+    return rows
+
+
+def part_rows(vsize, n_parts, part, band=BAND_SIZE):
+    return len(part_image_rows(vsize, n_parts, part, band))
+
+
+def assemble_bands(parts, frame, band=BAND_SIZE):
+    """Write the parts (one (rows, hsize, C) tensor per rank, bands back to back) to their places in
+    `frame` (vsize, hsize, C): one strided copy per rank for the whole rounds of bands, one more for
+    what is left."""
+    vsize = frame.shape[0]
+    n = len(parts)
+    rounds = vsize // (band * n)  # rounds in which every part has a whole band
+    if rounds:
+        grid = frame[: rounds * band * n].view(rounds, n, band, *frame.shape[1:])
+        for r, part in enumerate(parts):
+            grid[:, r] = part[: rounds * band].view(rounds, band, *frame.shape[1:])
+    for r, part in enumerate(parts):
+        rows = part_image_rows(vsize, n, r, band)[rounds * band:]
+        if rows:
+            frame[rows[0]: rows[0] + len(rows)] = part[rounds * band: rounds * band + len(rows)]
+    return frame
+
+
+def gather_parts(local, vsize, hsize, dst=0, group=None, out=None, band=BAND_SIZE):
+    """Every rank sends the bands it rendered (`local`: (part_rows, hsize, C)) to `dst`, which puts
+    them in their places; returns the (vsize, hsize, C) frame there and None elsewhere."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    chans = local.shape[-1]
+    sizes = [part_rows(vsize, world, r, band) for r in range(world)]
+    if local.shape[0] != sizes[rank] or local.shape[1] != hsize:
+        raise ValueError("local part has shape %s, expected (%d, %d, %d)" % (tuple(local.shape), sizes[rank], hsize, chans))
+    max_rows = max(sizes)
+    send = local
+    if sizes[rank] != max_rows:
+        send = torch.zeros((max_rows, hsize, chans), dtype=local.dtype, device=local.device)
+        send[: sizes[rank]] = local
+    send = send.contiguous()
+    if rank != dst:
+        dist.gather(send, gather_list=None, dst=dst, group=group)
+        return None
+    parts = [torch.empty_like(send) for _ in range(world)]
+    dist.gather(send, gather_list=parts, dst=dst, group=group)
+    frame = out if out is not None else torch.empty((vsize, hsize, chans), dtype=local.dtype, device=local.device)
+    return assemble_bands([p[:s] for p, s in zip(parts, sizes)], frame, band)

@@ -17,17 +17,6 @@ def part_image_rows(vsize, band, n_parts, part):
     return rows
 
 
-def test_part_rows_count(rta):
-    for vsize, band, n in [(2160, 10, 8), (4320, 10, 8), (97, 10, 3), (5, 10, 4), (100, 7, 16), (1, 1, 1)]:
-        total = 0
-        for p in range(n):
-            got = rta.rtx_part_rows(vsize, band, n, p)
-            assert got == len(part_image_rows(vsize, band, n, p))
-            total += got
-        assert total == vsize
-    assert rta.rtx_part_rows(100, 0, 4, 0) == 0 and rta.rtx_part_rows(100, 10, 4, 4) == 0
-
-
 @pytest.mark.parametrize("scene_name,W,H,n_parts", [("default", 250, 197, 3), ("glass", 320, 183, 8), ("random", 200, 120, 5)])
 def test_parts_reassemble_to_the_whole_frame(rta, orc, scene_name, W, H, n_parts):
     from ray_tracer_amd import scenes
