@@ -174,7 +174,19 @@ def main():
                 os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL prints a version banner on stdout when its communicator comes up; stdout is for the one
+        # JSON line, so the banner goes to stderr
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     n_gpus = world_size
     rta = entry.load_package()
     from ray_tracer_amd import sharding
@@ -247,6 +259,26 @@ def main():
         fence()
         render_only_wall = time.perf_counter() - t1
 
+    # the step once more with 8-bit RGBA pixels travelling instead of values (when that is not the step already)
+    rgba8_step_wall = None
+    if distributed and not fmt:
+        part8 = torch.empty((rows, W, 4), dtype=torch.uint8, device="cuda")
+        frame8 = torch.empty((H, W, 4), dtype=torch.uint8, device="cuda") if rank == 0 else None
+
+        def step8():
+            rta.render_part_device(ctx, scene, cd, args.depth, prec, sharding.BAND_SIZE, world_size, rank, rta.PIXELS_RGBA8,
+                                   part8.data_ptr(), part8.numel(), stream)
+            sharding.gather_parts(part8, H, W, dst=0, out=frame8)
+
+        for _ in range(max(2, args.warmup)):
+            step8()
+        fence()
+        t8 = time.perf_counter()
+        for _ in range(args.steps):
+            step8()
+        fence()
+        rgba8_step_wall = time.perf_counter() - t8
+
     # average device time of the dominant kernel (HIP events around it on its own stream)
     k_primary, k_all = [], []
     for _ in range(min(args.steps, 50)):
@@ -294,8 +326,8 @@ def main():
             rta._check(rta.rtx_render_8bit(ctx.h, scene.h, cd, args.depth, prec, 0, H, 4, rgba.ctypes.data, rgba.nbytes, None, None, None))
             host_rgba8_ms = min(host_rgba8_ms, (time.perf_counter() - t_h) * 1e3)
 
-    vals = torch.tensor([wall, float(st["color_rays"]), float(st["shadow_rays"]), render_only_wall or 0.0], dtype=torch.float64,
-                        device="cuda")
+    vals = torch.tensor([wall, float(st["color_rays"]), float(st["shadow_rays"]), render_only_wall or 0.0, rgba8_step_wall or 0.0],
+                        dtype=torch.float64, device="cuda")
     if distributed:
         mx = vals.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -303,6 +335,7 @@ def main():
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         wall = float(mx[0])
         render_only_wall = float(mx[3])
+        rgba8_step_wall = float(mx[4]) if rgba8_step_wall is not None else None
         color_rays, shadow_rays = int(sm[1]), int(sm[2])
     else:
         color_rays, shadow_rays = st["color_rays"], st["shadow_rays"]
@@ -386,6 +419,11 @@ def main():
             pixel_bytes = 4 if fmt else 3 * elem
             out["frame"]["gather_bytes"] = (H - sharding.part_rows(H, world_size, 0)) * W * pixel_bytes
             out["frame"]["gather_format"] = "rgba8" if fmt else args.precision
+            if rgba8_step_wall is not None:
+                # the same step when the ranks convert to RGBA8 before sending (a sixth of the f64 bytes)
+                out["frame"]["rgba8_gather_ms_per_step"] = rgba8_step_wall * 1e3 / args.steps
+                out["frame"]["rgba8_gather_Mrays_per_s"] = rays / (rgba8_step_wall / args.steps) / 1e6
+                out["frame"]["rgba8_gather_bytes"] = (H - sharding.part_rows(H, world_size, 0)) * W * 4
         if not args.no_cpu_baseline and n_gpus == 1:
             out["cpu_baseline"] = cpu_baseline(args.scene, W, H, args.depth, args.objects, args.cpu_seconds)
         if not args.no_extra and single and args.scene == "default" and args.precision == "f64":
