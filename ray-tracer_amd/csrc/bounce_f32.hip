@@ -5,3 +5,16 @@ namespace rtx {
 template hipError_t launch_bounce<float>(uint32_t, hipStream_t, const SceneDev<float> &, const QueueDev<float> &, const QueueDev<float> &,
                                        uint32_t, uint32_t, float *, StatShard *, uint32_t);
 }  // namespace rtx
+
+#ifdef RTX_PHASE_CLOCK
+extern "C" int rtx_debug_slow_rays_f32(double *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(rtx::g_slow_rays), sizeof(double) * 64 * 8) == hipSuccess ? 0 : -1;
+}
+extern "C" int rtx_debug_phase_bounce_f32(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rtx::g_phase), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(rtx::g_phase), z, sizeof z) != hipSuccess) return -1; }
+    return 0;
+}
+#endif

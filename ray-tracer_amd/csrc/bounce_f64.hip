@@ -9,3 +9,12 @@ namespace rtx {
 template hipError_t launch_bounce<double>(uint32_t, hipStream_t, const SceneDev<double> &, const QueueDev<double> &, const QueueDev<double> &,
                                        uint32_t, uint32_t, double *, StatShard *, uint32_t);
 }  // namespace rtx
+
+#ifdef RTX_PHASE_CLOCK
+extern "C" int rtx_debug_phase_bounce(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rtx::g_phase), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(rtx::g_phase), z, sizeof z) != hipSuccess) return -1; }
+    return 0;
+}
+#endif

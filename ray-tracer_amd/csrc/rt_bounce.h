@@ -77,6 +77,10 @@ RT_DEV void entry_take(const QueueChunk *lds, uint32_t wave, uint32_t lane, bool
 //   4. take the next block's entries from LDS (they arrived long ago), then add this block's
 //      weight * lighting to the framebuffer: the atomics are in flight while the next round
 //      computes.
+#ifdef RTX_PHASE_CLOCK
+static __device__ unsigned int g_slow_flag;
+static __device__ double g_slow_rays[64 * 8];
+#endif
 template <typename R, uint32_t SF>
 __global__ void __launch_bounds__(kRayBlock<R>)
 k_bounce(BounceArgs<R> args_in_kernarg_segment)
@@ -100,6 +104,11 @@ k_bounce(BounceArgs<R> args_in_kernarg_segment)
     uint32_t pixel = 0;
     bool first = true;
     RTX_PHASE_INIT();
+#ifdef RTX_PHASE_CLOCK
+    // one wave per launch compares the shader clock with the constant 100 MHz clock: the ratio
+    // is the frequency the chip ran at while this launch was resident
+    const unsigned long long clk0 = __builtin_readcyclecounter(), real0 = wall_clock64();
+#endif
     for (uint32_t base = blockIdx.x * kRayBlock<R>;; base += step) {
         // the compiler must not know that kp is the same pointer as in the last round, or it
         // hoists every load from it out of the loop (some fifty scalar registers)
@@ -150,6 +159,9 @@ k_bounce(BounceArgs<R> args_in_kernarg_segment)
         const uint32_t sub = (block + sub_in) & A.out_q.sub_mask;
         const R w = weight;
         const uint32_t px_index = pixel;
+#ifdef RTX_PHASE_CLOCK
+        const V3<R> dbg_o = ro, dbg_d = rd;
+#endif
         if (valid) {
             nd = trace_node<R, SF, false, kLaneWalk && (SF & SF_CULL) != 0>(A.S, nullptr, ro, rd, A.remaining, [&](const Node<R> &c) {
                 queue_push2(A.out_q, sub, c.has_reflect, c.over_point, c.reflectv, w * c.reflect_factor, c.has_refract,
@@ -165,12 +177,112 @@ k_bounce(BounceArgs<R> args_in_kernarg_segment)
             fb_add<R>(px + 2, nd.lighting.z * w);
         }
 #ifdef RTX_PHASE_CLOCK
+        {   // the longest round of any wave (a whole color_at node for 64 rays), and how many took over 100 000 cycles
+            const unsigned long long took = __builtin_readcyclecounter() - phase_t_;
+            if (phase_leader()) {
+                atomicMax(&g_phase[13], took);
+                if (took > 100000ull) atomicAdd(&g_phase[12], 1ull);
+            }
+            // the rays of the first wave whose round took over 3 million cycles
+            unsigned int claimed = 1u;
+            if (took > 3000000ull && phase_leader()) claimed = atomicCAS(&g_slow_flag, 0u, 1u);
+            claimed = __shfl(claimed, (int)(__ffsll((long long)__ballot(1)) - 1));
+            if (took > 3000000ull && claimed == 0u) {
+                double *o = g_slow_rays + (threadIdx.x & 63u) * 8;
+                o[0] = dbg_o.x; o[1] = dbg_o.y; o[2] = dbg_o.z; o[3] = dbg_d.x; o[4] = dbg_d.y; o[5] = dbg_d.z;
+                o[6] = valid ? 1.0 : 0.0; o[7] = (double)took;
+            }
+        }
         RTX_PHASE_MARK(5);  // a whole round, for the waves that reach here converged
 #endif
         if (!more) break;
     }
+#ifdef RTX_PHASE_CLOCK
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        atomicAdd(&g_phase[14], __builtin_readcyclecounter() - clk0);
+        atomicAdd(&g_phase[15], wall_clock64() - real0);
+    }
+#endif
     RTX_PHASE_FLUSH();
 }
+
+#ifdef RTX_SPLIT_BOUNCE
+// Experiment (tools build, -DRTX_SPLIT_BOUNCE; measured against the fused kernel in tools/README.md):
+// one recursion level as two launches with the hit record in memory between them -- the
+// intersect kernel finds every queued ray's closest hit, the shade kernel does the rest of the
+// color_at node.  One ray per thread, grids that cover the queues' capacity.
+template <typename R>
+struct alignas(16) HitRec {
+    R t;
+    uint32_t slot, obj, top1, top2, open, pad;
+};
+template <typename R>
+RT_DEV void entry_load(const QueueDev<R> &q, uint32_t sub, uint32_t idx, V3<R> &o, V3<R> &d, R &weight, uint32_t &pixel)
+{
+    const QueueChunk *src = reinterpret_cast<const QueueChunk *>(q.rec);
+    QueueChunk c[kEntryChunks<R>];
+    for (uint32_t j = 0; j < kEntryChunks<R>; ++j) c[j] = src[chunk_index(q, j, sub, idx)];
+    R v[8];
+    __builtin_memcpy(v, c, sizeof v);
+    o = { v[0], v[1], v[2] };
+    d = { v[3], v[4], v[5] };
+    weight = v[6];
+    pixel = pixel_bits_load<R>(v[7]);
+}
+template <typename R, uint32_t SF>
+__global__ void __launch_bounds__(kRayBlock<R>) k_split_intersect(BounceArgs<R> A, HitRec<R> *__restrict__ hits)
+{
+    const uint32_t sub = blockIdx.y;
+    uint32_t n = ro_load(A.in_q.count + (size_t)sub * kCountStride);
+    if (n > A.in_q.cap_sub) n = A.in_q.cap_sub;
+    if (blockIdx.x * kRayBlock<R> >= n) return;
+    const uint32_t k = blockIdx.x * kRayBlock<R> + threadIdx.x;
+    if (k >= n) return;
+    V3<R> ro, rd;
+    R weight;
+    uint32_t pixel;
+    entry_load(A.in_q, sub, k, ro, rd, weight, pixel);
+    const Hit<R> h = closest_hit<R, (SF & SF_TRANSPARENT) != 0, (SF & SF_CULL) != 0, (SF & SF_CHAIN) != 0>(A.S, ro, rd, Num<R>::inf);
+    HitRec<R> out = { h.t, h.slot, h.obj, h.top1, h.top2, h.hit_open ? 1u : 0u, 0u };
+    hits[(size_t)sub * A.in_q.cap_sub + k] = out;
+}
+template <typename R, uint32_t SF>
+__global__ void __launch_bounds__(kRayBlock<R>) k_split_shade(BounceArgs<R> A, const HitRec<R> *__restrict__ hits)
+{
+    const uint32_t sub_in = blockIdx.y;
+    uint32_t n = ro_load(A.in_q.count + (size_t)sub_in * kCountStride);
+    if (n > A.in_q.cap_sub) n = A.in_q.cap_sub;
+    if (blockIdx.x * kRayBlock<R> >= n) return;
+    const uint32_t k = blockIdx.x * kRayBlock<R> + threadIdx.x;
+    const bool valid = k < n;
+    Node<R> nd;
+    nd.hit = false;
+    nd.has_reflect = nd.has_refract = false;
+    nd.lighting = { R(0), R(0), R(0) };
+    R weight = R(0);
+    uint32_t pixel = 0;
+    const uint32_t sub = (blockIdx.x + sub_in) & A.out_q.sub_mask;
+    if (valid) {
+        V3<R> ro, rd;
+        entry_load(A.in_q, sub_in, k, ro, rd, weight, pixel);
+        const HitRec<R> r = hits[(size_t)sub_in * A.in_q.cap_sub + k];
+        Hit<R> h;
+        h.t = r.t; h.slot = r.slot; h.obj = r.obj; h.top1 = r.top1; h.top2 = r.top2; h.hit_open = r.open != 0u;
+        h.top1_t = h.top2_t = R(0);
+        nd = shade_node<R, SF, false, false>(A.S, ro, rd, A.remaining, h, [&](const Node<R> &c) {
+            queue_push2(A.out_q, sub, c.has_reflect, c.over_point, c.reflectv, weight * c.reflect_factor, c.has_refract, c.under_point,
+                        c.refract_dir, weight * c.refract_factor, pixel);
+        });
+        if (nd.hit) {
+            R *px = A.fb + (size_t)pixel * 3;
+            fb_add<R>(px + 0, nd.lighting.x * weight);
+            fb_add<R>(px + 1, nd.lighting.y * weight);
+            fb_add<R>(px + 2, nd.lighting.z * weight);
+        }
+    }
+    count_hits(A.stats, blockIdx.x + sub_in, A.level, valid && nd.hit);
+}
+#endif
 
 template <typename R>
 hipError_t launch_bounce(uint32_t sf, hipStream_t stream, const SceneDev<R> &scene, const QueueDev<R> &in_q,
@@ -183,6 +295,32 @@ hipError_t launch_bounce(uint32_t sf, hipStream_t stream, const SceneDev<R> &sce
     const uint32_t share = resident_blocks / n_sub > 0 ? resident_blocks / n_sub : 1u;
     const dim3 grid(worst < share ? worst : share, n_sub);
     const BounceArgs<R> args = { scene, in_q, out_q, remaining, level, fb, stats };
+#ifdef RTX_SPLIT_BOUNCE
+    {
+        static void *hit_buffer = nullptr;  // experiment: one buffer for the process, never shrunk (single-threaded use)
+        static size_t hit_bytes = 0;
+        const size_t need = (size_t)n_sub * in_q.cap_sub * sizeof(HitRec<R>);
+        if (need > hit_bytes) {
+            (void)hipDeviceSynchronize();
+            if (hit_buffer) (void)hipFree(hit_buffer);
+            hit_buffer = nullptr;
+            hit_bytes = 0;
+            const hipError_t e = hipMalloc(&hit_buffer, need);
+            if (e != hipSuccess) return e;
+            hit_bytes = need;
+        }
+        const dim3 full(worst, n_sub);
+        HitRec<R> *hits = static_cast<HitRec<R> *>(hit_buffer);
+#define RTX_CALL(SFV)                                                                                   \
+    if constexpr (((SFV) & (SF_REFLECTIVE | SF_TRANSPARENT)) != 0) {                                    \
+        hipLaunchKernelGGL((k_split_intersect<R, SFV | SF_PATTERN>), full, dim3(kRayBlock<R>), 0, stream, args, hits); \
+        hipLaunchKernelGGL((k_split_shade<R, SFV | SF_PATTERN>), full, dim3(kRayBlock<R>), 0, stream, args, hits);     \
+    }
+        RTX_SF_SWITCH(sf, RTX_CALL)
+#undef RTX_CALL
+        return hipGetLastError();
+    }
+#endif
 #define RTX_CALL(SFV)                                                                                   \
     if constexpr (((SFV) & (SF_REFLECTIVE | SF_TRANSPARENT)) != 0)                                      \
         hipLaunchKernelGGL((k_bounce<R, SFV | SF_PATTERN>), grid, dim3(kRayBlock<R>), table_lds_bytes(scene), stream, args)

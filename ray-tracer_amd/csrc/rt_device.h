@@ -1082,14 +1082,16 @@ __device__ __forceinline__ bool phase_leader() { return __builtin_amdgcn_mbcnt_h
 struct NoChildrenHook {
     template <typename N> RT_DEV void operator()(const N &) const {}
 };
+// Everything of a color_at node that follows the closest hit `h` of the ray (ro, rd).
+template <typename R, uint32_t SF, bool PRIMARY = false, bool LANE = false, typename Children = NoChildrenHook>
+RT_DEV Node<R> shade_node(const SceneDev<R> &S, V3<R> ro, V3<R> rd, uint32_t remaining, const Hit<R> &h,
+                          Children &&children = Children());
+
 template <typename R, uint32_t SF, bool PRIMARY = false, bool LANE = false, typename Children = NoChildrenHook>
 RT_DEV Node<R> trace_node(const SceneDev<R> &S, const PrimScene<R> *P, V3<R> ro, V3<R> rd, uint32_t remaining,
                           Children &&children = Children())
 {
     constexpr bool TRACK = (SF & SF_TRANSPARENT) != 0;
-    Node<R> nd;
-    nd.has_reflect = nd.has_refract = false;
-    nd.lighting = { R(0), R(0), R(0) };
     Hit<R> h;
     constexpr bool CULL = (SF & SF_CULL) != 0;
     constexpr bool CHAIN = (SF & SF_CHAIN) != 0;
@@ -1097,6 +1099,17 @@ RT_DEV Node<R> trace_node(const SceneDev<R> &S, const PrimScene<R> *P, V3<R> ro,
     if constexpr (PRIMARY) h = closest_hit_primary<R, TRACK, CULL, CHAIN>(S, *P, ro, rd);
     else h = closest_hit<R, TRACK, CULL, CHAIN, LANE>(S, ro, rd, Num<R>::inf);
     RTX_PHASE_MARK(PRIMARY ? 8 : 0);
+    return shade_node<R, SF, PRIMARY, LANE>(S, ro, rd, remaining, h, children);
+}
+
+template <typename R, uint32_t SF, bool PRIMARY, bool LANE, typename Children>
+RT_DEV Node<R> shade_node(const SceneDev<R> &S, V3<R> ro, V3<R> rd, uint32_t remaining, const Hit<R> &h, Children &&children)
+{
+    constexpr bool TRACK = (SF & SF_TRANSPARENT) != 0;
+    Node<R> nd;
+    nd.has_reflect = nd.has_refract = false;
+    nd.lighting = { R(0), R(0), R(0) };
+    RTX_PHASE_BEGIN();
     nd.hit = h.slot != kNone;
     nd.obj = h.obj;
     nd.t = h.t;

@@ -230,6 +230,20 @@ int grow(void **ptr, size_t *have, size_t need)
     return RTX_OK;
 }
 
+// The ray queues of slots that no call is using and nothing in flight refers to: given back when
+// another call cannot get its own (queues are sized for the worst case and kept for reuse, so a
+// few large frames on several host threads can hold tens of GB between them).
+void trim_idle_queues(rtx_context *ctx, const Workspace *keep)
+{
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    for (auto &s : ctx->slots) {
+        if (s->busy || s->pending || &s->ws == keep || !s->ws.queues) continue;
+        (void)hipFree(s->ws.queues);
+        s->ws.queues = nullptr;
+        s->ws.queue_bytes = 0;
+    }
+}
+
 // Device -> pageable host memory.  hipMemcpy stages such a copy through pinned memory with one
 // CPU thread (about 10-18 GB/s here); two pinned buffers, the DMA of one overlapping the memcpy
 // out of the other, and four threads on the memcpy reach about 50 GB/s.  Blocks until the data
@@ -772,6 +786,30 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Workspace &ws, hipEv
     const uint32_t W = cam ? cam->hsize : 0;
     int rc = plan_frame<R>(ws.fixed ? ws.queue_bytes : ctx->workspace_limit, scene->sf, max_depth, W, n_units, &plan);
     if (rc) return rc;
+    if (!ws.fixed && plan.bytes > ws.queue_bytes) {
+        // Not enough memory for the queues as planned: first take back what idle slots hold, then
+        // plan smaller chunks (half the limit at a time) before giving up.
+        size_t limit = ctx->workspace_limit;
+        for (int attempt = 0;; ++attempt) {
+            if (ws.queues) (void)hipFree(ws.queues);
+            ws.queues = nullptr;
+            ws.queue_bytes = 0;
+            if (hipMalloc(&ws.queues, plan.bytes) == hipSuccess) {
+                ws.queue_bytes = plan.bytes;
+                break;
+            }
+            (void)hipGetLastError();
+            ws.queues = nullptr;
+            if (attempt == 0) {
+                trim_idle_queues(ctx, &ws);
+                continue;
+            }
+            limit /= 2;
+            if (limit < ((size_t)64 << 20)) return fail(RTX_ERR_DEVICE, "out of device memory for the secondary-ray queues (%zu bytes)", plan.bytes);
+            rc = plan_frame<R>(limit, scene->sf, max_depth, W, n_units, &plan);
+            if (rc) return rc;
+        }
+    }
     if (format != 0u && plan.levels != 0u) return fail(RTX_ERR_INVALID, "internal: 8-bit output straight from a frame with secondary rays");
     if (ctx->debug_queue_divisor > 1)
         for (auto &c : plan.cap_sub) c = c ? std::max<uint64_t>(1, c / ctx->debug_queue_divisor) : 0;
