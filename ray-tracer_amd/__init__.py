@@ -136,6 +136,7 @@ rtx_render_device_noalloc = _bind("rtx_render_device_noalloc", C.c_int, [_vp, _v
 rtx_trace_rays = _bind("rtx_trace_rays", C.c_int, [_vp, _vp, _dp, C.c_size_t, C.c_uint32, C.c_int, _dp, C.POINTER(Stats)])
 rtx_probe_rays = _bind("rtx_probe_rays", C.c_int, [_vp, _vp, _dp, C.c_size_t, _vp])
 rtx_selfcheck_division = _bind("rtx_selfcheck_division", C.c_int, [_vp, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(C.c_uint64)])
+rtx_selfcheck_pow = _bind("rtx_selfcheck_pow", C.c_int, [_vp, C.c_uint64, C.c_uint32, _dp, _dp])
 rtx_generate_rays = _bind("rtx_generate_rays", C.c_int, [_vp, C.POINTER(CameraDesc), C.c_uint64, C.c_size_t, _dp])
 rtx_quantize_u8_device = _bind("rtx_quantize_u8_device", C.c_int, [_vp, _vp, C.c_int, C.c_size_t, _vp, _vp])
 
@@ -162,7 +163,7 @@ RTX_SYMBOLS = ["rtx_last_error", "rtx_context_create", "rtx_context_destroy", "r
                "rtx_context_set_debug_queue_divisor", "rtx_context_set_workspace_limit",
                "rtx_context_set_cull_threshold",
                "rtx_scene_upload", "rtx_scene_destroy", "rtx_scene_features", "rtx_render", "rtx_render_8bit", "rtx_render_device", "rtx_part_rows", "rtx_render_part_device", "rtx_render_device_noalloc", "rtx_trace_rays",
-               "rtx_probe_rays", "rtx_selfcheck_division", "rtx_generate_rays", "rtx_quantize_u8_device", "rtx_device_info", "rtx_multi_last_error", "rtx_multi_create",
+               "rtx_probe_rays", "rtx_selfcheck_division", "rtx_selfcheck_pow", "rtx_generate_rays", "rtx_quantize_u8_device", "rtx_device_info", "rtx_multi_last_error", "rtx_multi_create",
                "rtx_multi_destroy", "rtx_multi_device_count", "rtx_multi_scene_upload", "rtx_multi_scene_destroy", "rtx_multi_render"]
 
 

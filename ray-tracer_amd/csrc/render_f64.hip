@@ -112,6 +112,49 @@ hipError_t launch_check_div3(hipStream_t stream, uint64_t seed, uint32_t n, uint
     return hipGetLastError();
 }
 
+// Self-check of pow_specular against the general-purpose pow on n pseudo-random (x, y): x in
+// (0, 1] uniformly, or within 1e-3 of 1 (where specular highlights live), y among the common
+// shininess values and uniformly in [0, 2000].  out[0]: largest absolute difference, out[1]:
+// largest difference relative to the result (results above 1e-300), as the bits of non-negative
+// doubles (which order like integers).
+__global__ void __launch_bounds__(kBlock)
+k_check_pow(uint64_t seed, uint32_t n, unsigned long long *out)
+{
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= n) return;
+    uint64_t st = seed + (uint64_t)k * 0x9e3779b97f4a7c15ull;
+    auto next = [&]() {
+        st += 0x9e3779b97f4a7c15ull;
+        uint64_t z = st;
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        return z ^ (z >> 31);
+    };
+    auto unit = [&]() { return (double)((next() >> 11) + 1ull) * (1.0 / 9007199254740992.0); };  // (0, 1]
+    const double x = (next() % 3u) ? unit() : 1.0 - (unit() - 1.0 / 9007199254740992.0) * 1e-3;
+    const double common[5] = { 10.0, 50.0, 200.0, 300.0, 1000.0 };
+    const uint64_t pick = next() % 6u;
+    const double y = pick < 5u ? common[pick] : unit() * 2000.0;
+    const double got = pow_specular(x, y), want = pow(x, y);
+    const double diff = __builtin_fabs(got - want);
+    atomicMax(out + 0, __builtin_bit_cast(unsigned long long, diff));
+    if (want > 1e-300) atomicMax(out + 1, __builtin_bit_cast(unsigned long long, diff / want));
+    // the special cases: NaN in, NaN out; y = 0; a power that overflows; one that underflows
+    if (k == 0) {
+        const double nan = __builtin_nan("");
+        const double a = pow_specular(nan, 200.0), b = pow_specular(0.5, nan), c = pow_specular(0.3, 0.0),
+                     d = pow_specular(0.5, -5000.0), e = pow_specular(0.5, 5000.0), f = pow_specular(1.0, 1e300);
+        const bool ok = a != a && b != b && c == 1.0 && d == __builtin_huge_val() && e == 0.0 && f == 1.0;
+        if (!ok) atomicMax(out + 0, __builtin_bit_cast(unsigned long long, 1.0));
+    }
+}
+
+hipError_t launch_check_pow(hipStream_t stream, uint64_t seed, uint32_t n, unsigned long long *out)
+{
+    hipLaunchKernelGGL(k_check_pow, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, seed, n, out);
+    return hipGetLastError();
+}
+
 template struct Launch<double>;
 
 }  // namespace rtx

@@ -36,7 +36,7 @@ template <> struct Num<double> {
     static constexpr double inf = __builtin_huge_val();
     static RT_DEV double sqrt_(double x);  // below: the compiler's sequence without its range handling when x allows
     static RT_DEV double div(double a, double b) { return a / b; }
-    static RT_DEV double pow_(double a, double b) { return pow(a, b); }
+    static RT_DEV double pow_(double a, double b);  // below: pow_specular
     static RT_DEV double abs_(double x) { return __builtin_fabs(x); }
     static RT_DEV double floor_(double x) { return __builtin_floor(x); }
     static RT_DEV double max_(double a, double b) { return __builtin_fmax(a, b); }
@@ -124,6 +124,60 @@ RT_DEV double sqrt_steps(double x)
     return __builtin_fma(__builtin_fma(-g, g, x), h, g);
 }
 RT_DEV double Num<double>::sqrt_(double x) { return ordinary_radicand(x) ? sqrt_steps(x) : __builtin_sqrt(x); }
+// x^y of the specular term (factor = reflect_dot_eye.powf(shininess), src/scenes/lights.rs:70-72),
+// for x > 0.  The reference's powf is the host C library's pow; no device pow reproduces its bits
+// (the general-purpose one here is within 1 ulp of it and takes about 220 instructions, a tenth
+// of a color_at node), and the contract for colours is 1e-9.  This one is 2^(y log2 x) in plain
+// double arithmetic, about 60 instructions: log2 from the mantissa m in [sqrt(1/2), sqrt(2)) as
+// 2 atanh((m - 1) / (m + 1)) / ln 2, eleven terms; 2^f for |f| <= 1/2 as a 13th-degree Taylor
+// polynomial.  Its error relative to the true power is |y log2 x| * 5e-16 at most, and a result
+// that is not negligible has |y log2 x| < 40, so the factor, which lies in [0, 1], is off by
+// 1e-14 at most (measured against the general-purpose pow on the device: rtx_selfcheck_pow).
+// NaN gives NaN, y = 0 gives 1, overflow +inf, underflow 0.
+RT_DEV double pow_specular(double x, double y)
+{
+    double m = __builtin_amdgcn_frexp_mant(x);  // [1/2, 1)
+    int e = __builtin_amdgcn_frexp_exp(x);
+    const bool low = m < 0.70710678118654752;
+    m = low ? m + m : m;
+    e = low ? e - 1 : e;
+    const double s = (m - 1.0) * refined_rcp(m + 1.0);
+    const double z = s * s;
+    double p = 1.0 / 21.0;
+    p = __builtin_fma(p, z, 1.0 / 19.0);
+    p = __builtin_fma(p, z, 1.0 / 17.0);
+    p = __builtin_fma(p, z, 1.0 / 15.0);
+    p = __builtin_fma(p, z, 1.0 / 13.0);
+    p = __builtin_fma(p, z, 1.0 / 11.0);
+    p = __builtin_fma(p, z, 1.0 / 9.0);
+    p = __builtin_fma(p, z, 1.0 / 7.0);
+    p = __builtin_fma(p, z, 1.0 / 5.0);
+    p = __builtin_fma(p, z, 1.0 / 3.0);
+    p = __builtin_fma(p, z, 1.0);
+    const double log2x = __builtin_fma(s * 2.8853900817779268, p, (double)e);  // 2 / ln 2
+    const double t = y * log2x;
+    const double tc = __builtin_fmin(__builtin_fmax(t, -1100.0), 1100.0);
+    const double n = __builtin_rint(tc);
+    const double g = (tc - n) * 0.69314718055994531;
+    double q = 1.0 / 6227020800.0;
+    q = __builtin_fma(q, g, 1.0 / 479001600.0);
+    q = __builtin_fma(q, g, 1.0 / 39916800.0);
+    q = __builtin_fma(q, g, 1.0 / 3628800.0);
+    q = __builtin_fma(q, g, 1.0 / 362880.0);
+    q = __builtin_fma(q, g, 1.0 / 40320.0);
+    q = __builtin_fma(q, g, 1.0 / 5040.0);
+    q = __builtin_fma(q, g, 1.0 / 720.0);
+    q = __builtin_fma(q, g, 1.0 / 120.0);
+    q = __builtin_fma(q, g, 1.0 / 24.0);
+    q = __builtin_fma(q, g, 1.0 / 6.0);
+    q = __builtin_fma(q, g, 0.5);
+    q = __builtin_fma(q, g, 1.0);
+    q = __builtin_fma(q, g, 1.0);
+    double r = __builtin_ldexp(q, (int)n);
+    r = t == t ? r : t;
+    return y == 0.0 ? 1.0 : r;
+}
+RT_DEV double Num<double>::pow_(double a, double b) { return pow_specular(a, b); }
 // a / |a| (src/matrices/tuples.rs:58-73) with one range check for the root and the quotients: a
 // squared magnitude with an exponent in [-600, 600] has a root that is ordinary for the division
 RT_DEV V3<double> normalized(V3<double> a, double m2, double *length = nullptr)
@@ -383,14 +437,26 @@ RT_DEV double cull_fma(double a, double b, double c) { return __builtin_fma(a, b
 RT_DEV float cull_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 template <typename R>
 struct CullRay {
-    V3<R> o, u;  // origin, unit direction
+    V3<R> o, u;  // a point of the ray's line, unit direction
     R dlen;      // |d|: t of the ray times dlen is distance along u
-    bool dead;   // the ray holds a NaN: it cannot hit anything
+    R shift;     // o lies this far along u from the ray's origin (0: o is the origin)
+    bool dead;   // no object with a bounding sphere can be hit (a NaN in the ray, or all of them behind it)
 };
-template <typename R> RT_DEV CullRay<R> cull_ray(V3<R> o, V3<R> d)
+// Origins far from the scene make the sphere tests useless: the squared distance of a centre from
+// the line is a difference of two numbers of size |centre - origin|^2, and the allowance for its
+// rounding (and for that of the exact test, which grows the same way) then exceeds every radius.
+// A ray reflected towards the horizon meets a wall plane two million units away; its shadow ray
+// starts there, and in 24 bits every sphere of the scene "may be hit": such a wave walked all
+// 10 000 objects for a millisecond.  The fast path therefore tests a ray that starts outside the
+// sphere around all bounded objects from the point where its line reaches that sphere: the same
+// line up to the rounding of the move, which is no worse than that of the fast path's own
+// intersection tests at such an origin.  The exact path keeps the origin: there the allowance has
+// to cover the reference's arithmetic, which is evaluated from the true origin.
+template <typename R, bool LINE> RT_DEV CullRay<R> cull_ray(const SceneDev<R> &S, V3<R> o, V3<R> d)
 {
     CullRay<R> c;
     c.o = o;
+    c.shift = R(0);
     const R d2 = dot3(d, d);
     c.dlen = Num<R>::sqrt_(d2);
     // a zero or infinite direction gives NaNs here, with which no comparison below skips
@@ -401,6 +467,21 @@ template <typename R> RT_DEV CullRay<R> cull_ray(V3<R> o, V3<R> d)
     // comparisons are all false on NaN, would let such a ray through to all objects.
     const R oo = dot3(o, o);
     c.dead = !(d2 == d2) || !(oo == oo);
+    const V3<R> m = { S.world_c[0] - o.x, S.world_c[1] - o.y, S.world_c[2] - o.z };
+    const R m2 = cull_fma(m.z, m.z, cull_fma(m.y, m.y, m.x * m.x));
+    if (m2 > S.world_r * S.world_r) {  // the origin is outside (never true of a NaN or an infinite radius)
+        const R tc = cull_fma(m.z, c.u.z, cull_fma(m.y, c.u.y, m.x * c.u.x));
+        if constexpr (!LINE) c.dead = c.dead || tc < R(0);  // t^2 - 2 t tc + (m2 - r^2) > 0 for every t >= 0: the ray never enters
+        if constexpr (!Num<R>::exact) {
+            // Every point of the sphere is at least tc - world_r along u from the origin (before it, for
+            // intersections anywhere on the line): nothing bounded lies between the two points.
+            const R s = tc - S.world_r;
+            if (Num<R>::abs_(s) < Num<R>::big) {  // false for NaN
+                c.o = { cull_fma(c.u.x, s, o.x), cull_fma(c.u.y, s, o.y), cull_fma(c.u.z, s, o.z) };
+                c.shift = s;
+            }
+        }
+    }
     return c;
 }
 // LINE: intersections anywhere on the line count (the container bookkeeping of refraction reads
@@ -555,7 +636,7 @@ struct SphereCull {
     const R *best;
     R limit;
     const bool *stop;
-    RT_DEV R reach() const { return (best ? Num<R>::min_(*best, limit) : limit) * cr.dlen; }
+    RT_DEV R reach() const { return (best ? Num<R>::min_(*best, limit) : limit) * cr.dlen - cr.shift; }  // from cr.o
     struct Four {
         BoundRec<R> b[4];
     };
@@ -929,7 +1010,7 @@ RT_DEV Hit<R> closest_hit(const SceneDev<R> &S, V3<R> ro, V3<R> rd, R t_limit)
 {
     if constexpr (CULL) {
         return closest_hit_with<R, TRACK>(S, [&](const R *best, auto &&per) {
-            const SphereCull<R, TRACK> keep = { S.bnd, S.cl, S.grp, cull_ray(ro, rd), best, t_limit, nullptr };
+            const SphereCull<R, TRACK> keep = { S.bnd, S.cl, S.grp, cull_ray<R, TRACK>(S, ro, rd), best, t_limit, nullptr };
             walk_scene<R, CHAIN, LANE>(S, ro, rd, keep, per);
         });
     } else {
@@ -941,7 +1022,7 @@ RT_DEV Hit<R> closest_hit_primary(const SceneDev<R> &S, const PrimScene<R> &P, V
 {
     if constexpr (CULL) {
         return closest_hit_with<R, TRACK>(S, [&](const R *best, auto &&per) {
-            const SphereCull<R, TRACK> keep = { S.bnd, S.cl, S.grp, cull_ray(ro, rd), best, Num<R>::inf, nullptr };
+            const SphereCull<R, TRACK> keep = { S.bnd, S.cl, S.grp, cull_ray<R, TRACK>(S, ro, rd), best, Num<R>::inf, nullptr };
             walk_scene_primary<R, CHAIN>(S, P, ro, rd, keep, per);
         });
     } else {
@@ -965,7 +1046,7 @@ RT_DEV bool is_shadowed(const SceneDev<R> &S, V3<R> p, V3<R> dir, R distance)
             });
         };
         if constexpr (CULL) {
-            const SphereCull<R, false> keep = { S.bnd, S.cl, S.grp, cull_ray(p, dir), nullptr, distance, &shadowed };
+            const SphereCull<R, false> keep = { S.bnd, S.cl, S.grp, cull_ray<R, false>(S, p, dir), nullptr, distance, &shadowed };
             walk_scene<R, CHAIN, LANE>(S, p, dir, keep, per);
         } else {
             walk_scene<R, CHAIN>(S, p, dir, KeepAll(), per);

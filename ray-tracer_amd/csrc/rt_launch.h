@@ -92,6 +92,7 @@ hipError_t launch_probe(uint32_t sf, uint32_t grid, hipStream_t stream, const Sc
 
 // f64 only: counts operand sets on which the shared-reciprocal quotients differ from plain divisions.
 hipError_t launch_check_div3(hipStream_t stream, uint64_t seed, uint32_t n, uint32_t narrow, unsigned long long *mismatches);
+hipError_t launch_check_pow(hipStream_t stream, uint64_t seed, uint32_t n, unsigned long long *out);
 
 extern template struct Launch<double>;
 extern template struct Launch<float>;

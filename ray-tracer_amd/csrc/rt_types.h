@@ -162,6 +162,8 @@ struct SceneDev {
     uint32_t n_chn;
     R light_pos[3];
     R light_int[3];
+    R world_c[3];   // sphere around every object that has a finite bounding sphere (bounding-sphere
+    R world_r;      // tests only; +inf: none)
 };
 
 template <typename R>

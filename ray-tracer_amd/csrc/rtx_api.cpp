@@ -298,6 +298,8 @@ struct Tables {
     uint32_t cl_off[5] = { 0, 0, 0, 0, 0 }, grp_off[5] = { 0, 0, 0, 0, 0 };
     std::vector<uint32_t> slot_obj;
     std::vector<ColdRec<R>> cold;
+    // sphere around every bounded object (r = +inf: none, or no bounding-sphere tests)
+    double world_c[3] = { 0, 0, 0 }, world_r = std::numeric_limits<double>::infinity();
 };
 
 struct Bound {
@@ -579,6 +581,18 @@ void fill_tables(const rtx_scene_desc *d, const std::vector<uint8_t> &container,
         t.slot_obj.push_back(i);
         t.bnd.push_back(store(bounds[i].c, bounds[i].r));
     }
+    // The world sphere: around every object that has a finite sphere, with room for the inflation above.
+    std::vector<Bound> finite;
+    for (uint32_t i = 0; cull && i < n; ++i)
+        if (std::isfinite(bounds[i].r)) finite.push_back(bounds[i]);
+    if (!finite.empty()) {
+        const Bound w = enclosing_sphere(finite.data(), finite.size());
+        if (std::isfinite(w.r)) {
+            const double cmax = std::max(std::fabs(w.c[0]), std::max(std::fabs(w.c[1]), std::fabs(w.c[2])));
+            for (int k = 0; k < 3; ++k) t.world_c[k] = w.c[k];
+            t.world_r = w.r * (1.0 + 4.0 * rel) + cmax * 4.0 * ulp + 1e-3;
+        }
+    }
     // the walk fetches spheres four at a time: three entries of padding after the last
     const double zero[3] = { 0.0, 0.0, 0.0 };
     for (int k = 0; k < 3; ++k) {
@@ -645,6 +659,8 @@ int upload_tables(const Tables<R> &t, uint32_t sf, const rtx_scene_desc *d, void
     dev->n_con = (uint32_t)t.con.size();
     dev->n = d->n_objects;
     dev->flags = sf;
+    for (int k = 0; k < 3; ++k) dev->world_c[k] = (R)t.world_c[k];
+    dev->world_r = std::isfinite(t.world_r) ? (R)t.world_r : std::numeric_limits<R>::infinity();
     if (d->n_lights > 0 && d->light_position && d->light_intensity)
         for (int k = 0; k < 3; ++k) {
             dev->light_pos[k] = (R)d->light_position[k];
@@ -1538,6 +1554,31 @@ int rtx_selfcheck_division(rtx_context *ctx, uint64_t seed, uint32_t n, int narr
     HIP_TRY(hipStreamSynchronize(slot->stream));
     slot_settled(slot);
     *mismatches = count;
+    return RTX_OK;
+}
+
+int rtx_selfcheck_pow(rtx_context *ctx, uint64_t seed, uint32_t n, double *max_abs_diff, double *max_rel_diff)
+{
+    if (!ctx || !max_abs_diff || !max_rel_diff) return fail(RTX_ERR_INVALID, "ctx or an output pointer is NULL");
+    if (n == 0 || n > 0x7fffff00u) return fail(RTX_ERR_INVALID, "n must be between 1 and 2^31 - 256");
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return fail(RTX_ERR_DEVICE, "hipSetDevice(%d) failed", ctx->device);
+    SlotLease lease(ctx);
+    int rc = slot_acquire(ctx, &lease.slot);
+    if (rc) return rc;
+    Slot *slot = lease.slot;
+    rc = grow(&slot->aux, &slot->aux_bytes, 256);
+    if (rc) return rc;
+    rc = slot_order_after_pending(slot, slot->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(slot->aux, 0, 2 * sizeof(unsigned long long), slot->stream));
+    HIP_TRY(launch_check_pow(slot->stream, seed, n, (unsigned long long *)slot->aux));
+    double out[2] = { 0.0, 0.0 };
+    HIP_TRY(hipMemcpyAsync(out, slot->aux, sizeof out, hipMemcpyDeviceToHost, slot->stream));
+    HIP_TRY(hipStreamSynchronize(slot->stream));
+    slot_settled(slot);
+    *max_abs_diff = out[0];
+    *max_rel_diff = out[1];
     return RTX_OK;
 }
 

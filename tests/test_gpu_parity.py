@@ -636,3 +636,17 @@ def test_shared_reciprocal_quotients_are_the_bits_of_plain_divisions(rta, narrow
     for seed in (1, 0xDEADBEEF):
         rta._check(rta.rtx_selfcheck_division(ctx.h, seed, 1 << 22, narrow, C.byref(bad)))
         assert bad.value == 0
+
+
+@pytest.mark.gpu
+def test_specular_power_is_within_1e_13_of_the_general_pow(rta):
+    """lighting() raises reflect_dot_eye to the shininess (src/scenes/lights.rs:70-72); the f64 kernels
+    do it with a short 2^(y log2 x).  16M pairs against the device's general-purpose pow: the factor,
+    which lies in [0, 1], must agree to 1e-13 (colours are compared to 1e-9), NaN and y = 0 included."""
+    import ctypes as C
+    ctx = rta.Context(0)
+    worst_abs, worst_rel = C.c_double(-1.0), C.c_double(-1.0)
+    for seed in (7, 0xC0FFEE):
+        rta._check(rta.rtx_selfcheck_pow(ctx.h, seed, 1 << 23, C.byref(worst_abs), C.byref(worst_rel)))
+        assert 0.0 <= worst_abs.value < 1e-13, worst_abs.value
+        assert 0.0 <= worst_rel.value < 1e-11, worst_rel.value
