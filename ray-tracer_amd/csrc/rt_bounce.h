@@ -81,6 +81,17 @@ RT_DEV void entry_take(const QueueChunk *lds, uint32_t wave, uint32_t lane, bool
 static __device__ unsigned int g_slow_flag;
 static __device__ double g_slow_rays[64 * 8];
 #endif
+// dynamic LDS of a bounce launch: the shading table of a scene of at most kColdLds objects
+constexpr uint32_t kColdLds = 32;
+extern __shared__ __attribute__((aligned(16))) unsigned char rtx_lds_cold[];
+template <typename R> __host__ __device__ inline uint32_t cold_lds_bytes(const SceneDev<R> &S)
+{
+#ifdef RTX_NO_COLD_LDS
+    return 0u;
+#else
+    return S.n <= kColdLds ? S.n * (uint32_t)sizeof(ColdRec<R>) : 0u;
+#endif
+}
 template <typename R, uint32_t SF>
 __global__ void __launch_bounds__(kRayBlock<R>)
 k_bounce(BounceArgs<R> args_in_kernarg_segment)
@@ -99,6 +110,17 @@ k_bounce(BounceArgs<R> args_in_kernarg_segment)
 #ifdef RTX_LDS_TABLES
     if constexpr ((SF & SF_CULL) == 0) stage_tables<R>(args_in_kernarg_segment.S);
 #endif
+    // The shading records of a small scene are copied into LDS once per workgroup: the rays of a
+    // bounce wave hit different objects, and a per-lane gather of a 424-byte record from LDS costs
+    // a fraction of the same gather through the vector cache.
+    const bool cold_in_lds = cold_lds_bytes(args_in_kernarg_segment.S) != 0u;
+    if (cold_in_lds) {
+        const uint4 *from = reinterpret_cast<const uint4 *>(args_in_kernarg_segment.S.cold);
+        uint4 *to = reinterpret_cast<uint4 *>(rtx_lds_cold);
+        const uint32_t n16 = cold_lds_bytes(args_in_kernarg_segment.S) / 16u;
+        for (uint32_t i = threadIdx.x; i < n16; i += kRayBlock<R>) to[i] = from[i];
+        __syncthreads();
+    }
     V3<R> ro = { R(0), R(0), R(0) }, rd = ro;
     R weight = R(0);
     uint32_t pixel = 0;
@@ -115,6 +137,7 @@ k_bounce(BounceArgs<R> args_in_kernarg_segment)
         asm volatile("" : "+s"(kp));
         BounceArgs<R> A;
         __builtin_memcpy(&A, kp, sizeof A);
+        if (cold_in_lds) A.S.cold_lane = reinterpret_cast<const ColdRec<R> *>(rtx_lds_cold);
         uint32_t n = ro_load(A.in_q.count + (size_t)sub_in * kCountStride);
         if (n > A.in_q.cap_sub) n = A.in_q.cap_sub;
         // With bounding-sphere tests a wave walks the union of the spheres its rays can hit, one
@@ -323,7 +346,7 @@ hipError_t launch_bounce(uint32_t sf, hipStream_t stream, const SceneDev<R> &sce
 #endif
 #define RTX_CALL(SFV)                                                                                   \
     if constexpr (((SFV) & (SF_REFLECTIVE | SF_TRANSPARENT)) != 0)                                      \
-        hipLaunchKernelGGL((k_bounce<R, SFV | SF_PATTERN>), grid, dim3(kRayBlock<R>), table_lds_bytes(scene), stream, args)
+        hipLaunchKernelGGL((k_bounce<R, SFV | SF_PATTERN>), grid, dim3(kRayBlock<R>), table_lds_bytes(scene) + cold_lds_bytes(scene), stream, args)
     RTX_SF_SWITCH(sf, RTX_CALL)
 #undef RTX_CALL
     return hipGetLastError();

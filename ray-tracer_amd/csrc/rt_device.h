@@ -1055,7 +1055,7 @@ RT_DEV bool is_shadowed(const SceneDev<R> &S, V3<R> p, V3<R> dir, R distance)
     } else {
         Hit<R> h = closest_hit<R, false, CULL, CHAIN, LANE>(S, p, dir, distance);
         if (h.slot == kNone) return false;
-        return h.t < distance && (S.cold[h.obj].flags & OF_CASTS_SHADOW) != 0;
+        return h.t < distance && (S.cold_lane[h.obj].flags & OF_CASTS_SHADOW) != 0;
     }
 }
 
@@ -1196,7 +1196,7 @@ RT_DEV Node<R> shade_node(const SceneDev<R> &S, V3<R> ro, V3<R> rd, uint32_t rem
     nd.t = h.t;
     if (!nd.hit) return nd;
 
-    const ColdRec<R> &cold = S.cold[h.obj];
+    const ColdRec<R> &cold = S.cold_lane[h.obj];
 
     // prepare_computations, world.rs:242-251; Ray::position, rays.rs:24-28
     V3<R> pt = { ro.x + rd.x * h.t, ro.y + rd.y * h.t, ro.z + rd.z * h.t };
@@ -1232,10 +1232,10 @@ RT_DEV Node<R> shade_node(const SceneDev<R> &S, V3<R> ro, V3<R> rd, uint32_t rem
 
     R n1 = R(1), n2 = R(1);
     if constexpr (TRACK) {
-        if (h.top1 != kNone) n1 = S.cold[S.slot_obj[h.top1]].refractive_index;
+        if (h.top1 != kNone) n1 = S.cold_lane[S.slot_obj[h.top1]].refractive_index;
         if (!h.hit_open) n2 = cold.refractive_index;
-        else if (h.top1 != h.slot) n2 = S.cold[S.slot_obj[h.top1]].refractive_index;
-        else if (h.top2 != kNone) n2 = S.cold[S.slot_obj[h.top2]].refractive_index;
+        else if (h.top1 != h.slot) n2 = S.cold_lane[S.slot_obj[h.top1]].refractive_index;
+        else if (h.top2 != kNone) n2 = S.cold_lane[S.slot_obj[h.top2]].refractive_index;
     }
 
     nd.point = pt; nd.normalv = normalv; nd.over_point = over; nd.under_point = under; nd.reflectv = reflectv;
