@@ -81,19 +81,13 @@ RT_DEV void entry_take(const QueueChunk *lds, uint32_t wave, uint32_t lane, bool
 static __device__ unsigned int g_slow_flag;
 static __device__ double g_slow_rays[64 * 8];
 #endif
-// dynamic LDS of a bounce launch: the shading table of a scene of at most kColdLds objects
-constexpr uint32_t kColdLds = 32;
-extern __shared__ __attribute__((aligned(16))) unsigned char rtx_lds_cold[];
-template <typename R> __host__ __device__ inline uint32_t cold_lds_bytes(const SceneDev<R> &S)
-{
-#ifdef RTX_NO_COLD_LDS
-    return 0u;
-#else
-    return S.n <= kColdLds ? S.n * (uint32_t)sizeof(ColdRec<R>) : 0u;
+// COLD_LDS: the launch comes with cold_lds_bytes() of dynamic LDS and the scene has at most
+// kColdLdsObjects objects (launch_bounce sees to both).
+#ifndef RTX_BOUNCE_ATTR  // occupancy experiments, e.g. -DRTX_BOUNCE_ATTR='__attribute__((amdgpu_waves_per_eu(5,5)))'
+#define RTX_BOUNCE_ATTR
 #endif
-}
-template <typename R, uint32_t SF>
-__global__ void __launch_bounds__(kRayBlock<R>)
+template <typename R, uint32_t SF, bool COLD_LDS>
+__global__ void __launch_bounds__(kRayBlock<R>) RTX_BOUNCE_ATTR
 k_bounce(BounceArgs<R> args_in_kernarg_segment)
 {
     __shared__ QueueChunk lds[kRayBlock<R> * kEntryChunks<R>];
@@ -110,17 +104,7 @@ k_bounce(BounceArgs<R> args_in_kernarg_segment)
 #ifdef RTX_LDS_TABLES
     if constexpr ((SF & SF_CULL) == 0) stage_tables<R>(args_in_kernarg_segment.S);
 #endif
-    // The shading records of a small scene are copied into LDS once per workgroup: the rays of a
-    // bounce wave hit different objects, and a per-lane gather of a 424-byte record from LDS costs
-    // a fraction of the same gather through the vector cache.
-    const bool cold_in_lds = cold_lds_bytes(args_in_kernarg_segment.S) != 0u;
-    if (cold_in_lds) {
-        const uint4 *from = reinterpret_cast<const uint4 *>(args_in_kernarg_segment.S.cold);
-        uint4 *to = reinterpret_cast<uint4 *>(rtx_lds_cold);
-        const uint32_t n16 = cold_lds_bytes(args_in_kernarg_segment.S) / 16u;
-        for (uint32_t i = threadIdx.x; i < n16; i += kRayBlock<R>) to[i] = from[i];
-        __syncthreads();
-    }
+    if constexpr (COLD_LDS) stage_cold_table<R>(args_in_kernarg_segment.S, kRayBlock<R>);
     V3<R> ro = { R(0), R(0), R(0) }, rd = ro;
     R weight = R(0);
     uint32_t pixel = 0;
@@ -137,7 +121,6 @@ k_bounce(BounceArgs<R> args_in_kernarg_segment)
         asm volatile("" : "+s"(kp));
         BounceArgs<R> A;
         __builtin_memcpy(&A, kp, sizeof A);
-        if (cold_in_lds) A.S.cold_lane = reinterpret_cast<const ColdRec<R> *>(rtx_lds_cold);
         uint32_t n = ro_load(A.in_q.count + (size_t)sub_in * kCountStride);
         if (n > A.in_q.cap_sub) n = A.in_q.cap_sub;
         // With bounding-sphere tests a wave walks the union of the spheres its rays can hit, one
@@ -186,14 +169,18 @@ k_bounce(BounceArgs<R> args_in_kernarg_segment)
         const V3<R> dbg_o = ro, dbg_d = rd;
 #endif
         if (valid) {
-            nd = trace_node<R, SF, false, kLaneWalk && (SF & SF_CULL) != 0>(A.S, nullptr, ro, rd, A.remaining, [&](const Node<R> &c) {
+            nd = trace_node<R, SF, false, kLaneWalk && (SF & SF_CULL) != 0, COLD_LDS>(A.S, nullptr, ro, rd, A.remaining, [&](const Node<R> &c) {
                 queue_push2(A.out_q, sub, c.has_reflect, c.over_point, c.reflectv, w * c.reflect_factor, c.has_refract,
                             c.under_point, c.refract_dir, w * c.refract_factor, px_index);
             });
         }
         count_hits(A.stats, block + sub_in, A.level, valid && nd.hit);
         entry_take<R>(lds, wave, lane, valid_next, ro, rd, weight, pixel);
+#ifdef RTX_EXP_NO_FB_ADD  // knock-out experiment: the frame is wrong, the time shows what the atomics cost
+        if (valid && nd.hit && nd.lighting.x * w == R(-12345)) {
+#else
         if (valid && nd.hit) {
+#endif
             R *px = A.fb + (size_t)px_index * 3;
             fb_add<R>(px + 0, nd.lighting.x * w);
             fb_add<R>(px + 1, nd.lighting.y * w);
@@ -292,7 +279,7 @@ __global__ void __launch_bounds__(kRayBlock<R>) k_split_shade(BounceArgs<R> A, c
         Hit<R> h;
         h.t = r.t; h.slot = r.slot; h.obj = r.obj; h.top1 = r.top1; h.top2 = r.top2; h.hit_open = r.open != 0u;
         h.top1_t = h.top2_t = R(0);
-        nd = shade_node<R, SF, false, false>(A.S, ro, rd, A.remaining, h, [&](const Node<R> &c) {
+        nd = shade_node<R, SF, false, false, false>(A.S, ro, rd, A.remaining, h, [&](const Node<R> &c) {
             queue_push2(A.out_q, sub, c.has_reflect, c.over_point, c.reflectv, weight * c.reflect_factor, c.has_refract, c.under_point,
                         c.refract_dir, weight * c.refract_factor, pixel);
         });
@@ -344,9 +331,25 @@ hipError_t launch_bounce(uint32_t sf, hipStream_t stream, const SceneDev<R> &sce
         return hipGetLastError();
     }
 #endif
+    // Scenes small enough keep their shading table in LDS; only the variants without bounding-sphere
+    // tests exist in that form (a scene with those tests has at least 16 objects and usually thousands).
+    const uint32_t cold_bytes =
+#ifdef RTX_LDS_TABLES
+        0u;  // that experiment uses the dynamic LDS for the intersection tables
+#else
+        (sf & SF_CULL) ? 0u : cold_lds_bytes<R>(scene.n);
+#endif
 #define RTX_CALL(SFV)                                                                                   \
-    if constexpr (((SFV) & (SF_REFLECTIVE | SF_TRANSPARENT)) != 0)                                      \
-        hipLaunchKernelGGL((k_bounce<R, SFV | SF_PATTERN>), grid, dim3(kRayBlock<R>), table_lds_bytes(scene) + cold_lds_bytes(scene), stream, args)
+    if constexpr (((SFV) & (SF_REFLECTIVE | SF_TRANSPARENT)) != 0) {                                    \
+        if constexpr (((SFV) & SF_CULL) == 0) {                                                         \
+            if (cold_bytes)                                                                             \
+                hipLaunchKernelGGL((k_bounce<R, SFV | SF_PATTERN, true>), grid, dim3(kRayBlock<R>), cold_bytes, stream, args); \
+            else                                                                                        \
+                hipLaunchKernelGGL((k_bounce<R, SFV | SF_PATTERN, false>), grid, dim3(kRayBlock<R>), table_lds_bytes(scene), stream, args); \
+        } else {                                                                                        \
+            hipLaunchKernelGGL((k_bounce<R, SFV | SF_PATTERN, false>), grid, dim3(kRayBlock<R>), table_lds_bytes(scene), stream, args); \
+        }                                                                                               \
+    }
     RTX_SF_SWITCH(sf, RTX_CALL)
 #undef RTX_CALL
     return hipGetLastError();

@@ -220,13 +220,14 @@ template <typename R> RT_DEV V3<R> normalize3(V3<R> a)
     }
 }
 // src/matrices/matrix4.rs:172-193 for a point (w = 1) and a vector (w = 0); m = 3 rows x 4
-template <typename R> RT_DEV V3<R> xform_point(const R *m, V3<R> p)
+// (M: a pointer to the matrix in any address space)
+template <typename R, typename M> RT_DEV V3<R> xform_point(M m, V3<R> p)
 {
     return { ((m[0] * p.x + m[1] * p.y) + m[2] * p.z) + m[3],
              ((m[4] * p.x + m[5] * p.y) + m[6] * p.z) + m[7],
              ((m[8] * p.x + m[9] * p.y) + m[10] * p.z) + m[11] };
 }
-template <typename R> RT_DEV V3<R> xform_vector(const R *m, V3<R> v)
+template <typename R, typename M> RT_DEV V3<R> xform_vector(M m, V3<R> v)
 {
     return { (m[0] * v.x + m[1] * v.y) + m[2] * v.z,
              (m[4] * v.x + m[5] * v.y) + m[6] * v.z,
@@ -927,6 +928,42 @@ RT_DEV void make_primary_record(const SceneDev<R> &S, const PrimScene<R> &P, V3<
     const_cast<PrimCappedRec<R> *>(is_cyl ? P.cyl : P.con)[i] = out;
 }
 
+// Where a kernel reads the shading records from.  The rays of a bounce wave hit different
+// objects, so the record of a hit is gathered per lane, 424 bytes (f64) from 64 places: through
+// the vector cache that is some 1700 separate accesses per wave and node, and the cache's
+// address unit, not the arithmetic, sets the pace.  Kernels instantiated with COLD_LDS copy the
+// table of a small scene into LDS when a workgroup starts (stage_cold_table) and gather from
+// there with LDS reads; the others read the table in memory.
+extern __shared__ __attribute__((aligned(16))) unsigned char rtx_lds_dyn[];
+constexpr uint32_t kColdLdsObjects = 32;  // largest scene whose shading table a workgroup keeps in LDS
+// The copy holds the shading records, then the slot -> object index table (as many entries).
+template <typename R> __host__ __device__ inline uint32_t cold_lds_bytes(uint32_t n_objects)
+{
+    return n_objects <= kColdLdsObjects ? n_objects * (uint32_t)(sizeof(ColdRec<R>) + sizeof(uint32_t)) : 0u;
+}
+template <typename R, bool COLD_LDS> struct ColdTable {
+    using Rec = const ColdRec<R>;
+    using Index = const uint32_t;
+    static RT_DEV Rec *base(const SceneDev<R> &S) { return S.cold; }
+    static RT_DEV Index *slot_obj(const SceneDev<R> &S) { return S.slot_obj; }
+};
+template <typename R> struct ColdTable<R, true> {
+    using Rec = const __attribute__((address_space(3))) ColdRec<R>;
+    using Index = const __attribute__((address_space(3))) uint32_t;
+    static RT_DEV Rec *base(const SceneDev<R> &) { return (Rec *)rtx_lds_dyn; }
+    static RT_DEV Index *slot_obj(const SceneDev<R> &S) { return (Index *)(rtx_lds_dyn + S.n * (uint32_t)sizeof(ColdRec<R>)); }
+};
+template <typename R> RT_DEV void stage_cold_table(const SceneDev<R> &S, uint32_t n_threads)
+{
+    const uint4 *from = reinterpret_cast<const uint4 *>(S.cold);
+    uint4 *to = reinterpret_cast<uint4 *>(rtx_lds_dyn);
+    const uint32_t n16 = S.n * (uint32_t)sizeof(ColdRec<R>) / 16u;
+    for (uint32_t i = threadIdx.x; i < n16; i += n_threads) to[i] = from[i];
+    uint32_t *index = reinterpret_cast<uint32_t *>(rtx_lds_dyn + S.n * (uint32_t)sizeof(ColdRec<R>));
+    for (uint32_t i = threadIdx.x; i < S.n; i += n_threads) index[i] = S.slot_obj[i];
+    __syncthreads();
+}
+
 // ---- closest hit over the whole world ---------------------------------------------------
 // The reference concatenates every object's intersections, stable-sorts by t and takes the
 // first t >= 0 (src/scenes/world.rs:98-119): the smallest t >= 0, and among equal t the object
@@ -951,7 +988,7 @@ struct Hit {
 
 constexpr uint32_t kNone = 0xffffffffu;
 
-template <typename R, bool TRACK, typename Walk>
+template <typename R, bool TRACK, bool COLD_LDS = false, typename Walk>
 RT_DEV Hit<R> closest_hit_with(const SceneDev<R> &S, Walk &&walk)
 {
     Hit<R> h;
@@ -1000,21 +1037,24 @@ RT_DEV Hit<R> closest_hit_with(const SceneDev<R> &S, Walk &&walk)
             }
         }
     });
-    if (h.slot != kNone) h.obj = ro_load(S.slot_obj + h.slot);
+    if (h.slot != kNone) {
+        if constexpr (COLD_LDS) h.obj = ColdTable<R, true>::slot_obj(S)[h.slot];
+        else h.obj = ro_load(S.slot_obj + h.slot);
+    }
     return h;
 }
 // The closest-hit walks.  t_limit: hits beyond it need not be found (inf for color_at; the
 // distance to the light for a shadow ray, which only asks whether the closest hit lies before it).
-template <typename R, bool TRACK, bool CULL, bool CHAIN, bool LANE = false>
+template <typename R, bool TRACK, bool CULL, bool CHAIN, bool LANE = false, bool COLD_LDS = false>
 RT_DEV Hit<R> closest_hit(const SceneDev<R> &S, V3<R> ro, V3<R> rd, R t_limit)
 {
     if constexpr (CULL) {
-        return closest_hit_with<R, TRACK>(S, [&](const R *best, auto &&per) {
+        return closest_hit_with<R, TRACK, COLD_LDS>(S, [&](const R *best, auto &&per) {
             const SphereCull<R, TRACK> keep = { S.bnd, S.cl, S.grp, cull_ray<R, TRACK>(S, ro, rd), best, t_limit, nullptr };
             walk_scene<R, CHAIN, LANE>(S, ro, rd, keep, per);
         });
     } else {
-        return closest_hit_with<R, TRACK>(S, [&](const R *, auto &&per) { walk_scene<R, CHAIN>(S, ro, rd, KeepAll(), per); });
+        return closest_hit_with<R, TRACK, COLD_LDS>(S, [&](const R *, auto &&per) { walk_scene<R, CHAIN>(S, ro, rd, KeepAll(), per); });
     }
 }
 template <typename R, bool TRACK, bool CULL, bool CHAIN>
@@ -1033,7 +1073,7 @@ RT_DEV Hit<R> closest_hit_primary(const SceneDev<R> &S, const PrimScene<R> &P, V
 // src/scenes/world.rs:146-158.  shadowed iff the closest hit (t >= 0) lies before the light
 // and its object casts a shadow.  When every object casts, any hit with 0 <= t < distance
 // decides it, so the walk needs no closest-hit bookkeeping.
-template <typename R, uint32_t SF, bool LANE = false>
+template <typename R, uint32_t SF, bool LANE = false, bool COLD_LDS = false>
 RT_DEV bool is_shadowed(const SceneDev<R> &S, V3<R> p, V3<R> dir, R distance)
 {
     constexpr bool CULL = (SF & SF_CULL) != 0;
@@ -1053,9 +1093,9 @@ RT_DEV bool is_shadowed(const SceneDev<R> &S, V3<R> p, V3<R> dir, R distance)
         }
         return shadowed;
     } else {
-        Hit<R> h = closest_hit<R, false, CULL, CHAIN, LANE>(S, p, dir, distance);
+        Hit<R> h = closest_hit<R, false, CULL, CHAIN, LANE, COLD_LDS>(S, p, dir, distance);
         if (h.slot == kNone) return false;
-        return h.t < distance && (S.cold_lane[h.obj].flags & OF_CASTS_SHADOW) != 0;
+        return h.t < distance && (ColdTable<R, COLD_LDS>::base(S)[h.obj].flags & OF_CASTS_SHADOW) != 0;
     }
 }
 
@@ -1164,11 +1204,11 @@ struct NoChildrenHook {
     template <typename N> RT_DEV void operator()(const N &) const {}
 };
 // Everything of a color_at node that follows the closest hit `h` of the ray (ro, rd).
-template <typename R, uint32_t SF, bool PRIMARY = false, bool LANE = false, typename Children = NoChildrenHook>
+template <typename R, uint32_t SF, bool PRIMARY = false, bool LANE = false, bool COLD_LDS = false, typename Children = NoChildrenHook>
 RT_DEV Node<R> shade_node(const SceneDev<R> &S, V3<R> ro, V3<R> rd, uint32_t remaining, const Hit<R> &h,
                           Children &&children = Children());
 
-template <typename R, uint32_t SF, bool PRIMARY = false, bool LANE = false, typename Children = NoChildrenHook>
+template <typename R, uint32_t SF, bool PRIMARY = false, bool LANE = false, bool COLD_LDS = false, typename Children = NoChildrenHook>
 RT_DEV Node<R> trace_node(const SceneDev<R> &S, const PrimScene<R> *P, V3<R> ro, V3<R> rd, uint32_t remaining,
                           Children &&children = Children())
 {
@@ -1178,12 +1218,12 @@ RT_DEV Node<R> trace_node(const SceneDev<R> &S, const PrimScene<R> *P, V3<R> ro,
     constexpr bool CHAIN = (SF & SF_CHAIN) != 0;
     RTX_PHASE_BEGIN();
     if constexpr (PRIMARY) h = closest_hit_primary<R, TRACK, CULL, CHAIN>(S, *P, ro, rd);
-    else h = closest_hit<R, TRACK, CULL, CHAIN, LANE>(S, ro, rd, Num<R>::inf);
+    else h = closest_hit<R, TRACK, CULL, CHAIN, LANE, COLD_LDS>(S, ro, rd, Num<R>::inf);
     RTX_PHASE_MARK(PRIMARY ? 8 : 0);
-    return shade_node<R, SF, PRIMARY, LANE>(S, ro, rd, remaining, h, children);
+    return shade_node<R, SF, PRIMARY, LANE, COLD_LDS>(S, ro, rd, remaining, h, children);
 }
 
-template <typename R, uint32_t SF, bool PRIMARY, bool LANE, typename Children>
+template <typename R, uint32_t SF, bool PRIMARY, bool LANE, bool COLD_LDS, typename Children>
 RT_DEV Node<R> shade_node(const SceneDev<R> &S, V3<R> ro, V3<R> rd, uint32_t remaining, const Hit<R> &h, Children &&children)
 {
     constexpr bool TRACK = (SF & SF_TRANSPARENT) != 0;
@@ -1196,7 +1236,9 @@ RT_DEV Node<R> shade_node(const SceneDev<R> &S, V3<R> ro, V3<R> rd, uint32_t rem
     nd.t = h.t;
     if (!nd.hit) return nd;
 
-    const ColdRec<R> &cold = S.cold_lane[h.obj];
+    typename ColdTable<R, COLD_LDS>::Rec *const cold_table = ColdTable<R, COLD_LDS>::base(S);
+    typename ColdTable<R, COLD_LDS>::Rec &cold = cold_table[h.obj];
+    typename ColdTable<R, COLD_LDS>::Index *const slot_obj = ColdTable<R, COLD_LDS>::slot_obj(S);
 
     // prepare_computations, world.rs:242-251; Ray::position, rays.rs:24-28
     V3<R> pt = { ro.x + rd.x * h.t, ro.y + rd.y * h.t, ro.z + rd.z * h.t };
@@ -1232,10 +1274,10 @@ RT_DEV Node<R> shade_node(const SceneDev<R> &S, V3<R> ro, V3<R> rd, uint32_t rem
 
     R n1 = R(1), n2 = R(1);
     if constexpr (TRACK) {
-        if (h.top1 != kNone) n1 = S.cold_lane[S.slot_obj[h.top1]].refractive_index;
+        if (h.top1 != kNone) n1 = cold_table[slot_obj[h.top1]].refractive_index;
         if (!h.hit_open) n2 = cold.refractive_index;
-        else if (h.top1 != h.slot) n2 = S.cold_lane[S.slot_obj[h.top1]].refractive_index;
-        else if (h.top2 != kNone) n2 = S.cold_lane[S.slot_obj[h.top2]].refractive_index;
+        else if (h.top1 != h.slot) n2 = cold_table[slot_obj[h.top1]].refractive_index;
+        else if (h.top2 != kNone) n2 = cold_table[slot_obj[h.top2]].refractive_index;
     }
 
     nd.point = pt; nd.normalv = normalv; nd.over_point = over; nd.under_point = under; nd.reflectv = reflectv;
@@ -1302,7 +1344,7 @@ RT_DEV Node<R> shade_node(const SceneDev<R> &S, V3<R> ro, V3<R> rd, uint32_t rem
     V3<R> lvec = { S.light_pos[0] - over.x, S.light_pos[1] - over.y, S.light_pos[2] - over.z };
     R ldist;
     V3<R> lightv = normalized(lvec, (lvec.x * lvec.x + lvec.y * lvec.y) + lvec.z * lvec.z, &ldist);
-    bool shadowed = is_shadowed<R, SF, LANE>(S, over, lightv, ldist);
+    bool shadowed = is_shadowed<R, SF, LANE, COLD_LDS>(S, over, lightv, ldist);
     nd.shadowed = shadowed;
     RTX_PHASE_MARK(PRIMARY ? 11 : 3);
 

@@ -156,8 +156,6 @@ struct SceneDev {
     uint32_t grp_off[5];
     const uint32_t *slot_obj;  // slot -> index in World.objects (the tie-break order among equal t)
     const ColdRec<R> *cold;    // by index in World.objects
-    const ColdRec<R> *cold_lane;  // the same table as the per-lane gathers of a shaded hit read it: a kernel may
-                               // point this at a copy in LDS (generic address); elsewhere it equals cold
     uint32_t n_sph, n_pln, n_cub, n_cyl, n_con;
     uint32_t n;
     uint32_t flags;

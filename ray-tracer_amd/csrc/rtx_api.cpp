@@ -643,7 +643,6 @@ int upload_tables(const Tables<R> &t, uint32_t sf, const rtx_scene_desc *d, void
     dev->con = (const CappedRec<R> *)(base + o_con);
     dev->slot_obj = (const uint32_t *)(base + o_slot);
     dev->cold = (const ColdRec<R> *)(base + o_cold);
-    dev->cold_lane = dev->cold;
     dev->bnd = (const BoundRec<R> *)(base + o_bnd);
     dev->cl = (const BoundRec<R> *)(base + o_cl);
     dev->grp = (const BoundRec<R> *)(base + o_grp);
