@@ -448,28 +448,40 @@ def extra_scenes(rta, ctx, args):
     res = {}
     cases = [("default", "f32", {}), ("spheres_on_plane", "f64", {}), ("glass", "f64", {}), ("glass", "f32", {}),
              ("random", "f64", {"objects": 10000}), ("random", "f32", {"objects": 10000})]
-    for name, precision, kw in cases:
+    never = (1 << 64) - 1
+
+    def frame_time(name, precision, kw, measured_above=None):
         prec = rta.F64 if precision == "f64" else rta.F32
         tdtype = torch.float64 if prec == rta.F64 else torch.float32
         world, cam = build_scene(rta, name, args.width, args.height, kw.get("objects", args.objects))
         flat = rta.flatten(world)
-        scene = rta.Scene(ctx, flat)
+        own = rta.Context(torch.cuda.current_device())  # a context of its own: what it holds afterwards is this scene's
+        if measured_above is not None:
+            own.set_measured_queues(measured_above)
+        scene = rta.Scene(own, flat)
         cd = rta.camera_desc(cam)
         tile = torch.empty((args.height, args.width, 3), dtype=tdtype, device="cuda")
         nbytes = tile.numel() * tile.element_size()
         st = {}
-        rta.render_device(ctx, scene, cd, args.depth, prec, 0, args.height, tile.data_ptr(), nbytes, None, st)
+        rta.render_device(own, scene, cd, args.depth, prec, 0, args.height, tile.data_ptr(), nbytes, None, st)
         frames = 3 if st["kernel_ms"] > 50 else 20
         times = []
         for _ in range(frames):
             s2 = {}
-            rta.render_device(ctx, scene, cd, args.depth, prec, 0, args.height, tile.data_ptr(), nbytes, None, s2)
+            rta.render_device(own, scene, cd, args.depth, prec, 0, args.height, tile.data_ptr(), nbytes, None, s2)
             times.append(s2["kernel_ms"])
-        ms = float(np.median(times))
+        culled = bool(scene.features()["bounding_sphere_tests"])
+        queue_gb = own.queue_bytes() / 1e9
+        scene.close()
+        own.close()
+        return float(np.median(times)), st, flat, culled, queue_gb
+
+    for name, precision, kw in cases:
+        ms, st, flat, culled, queue_gb = frame_time(name, precision, kw)
+        prec = rta.F64 if precision == "f64" else rta.F32
         rays = st["color_rays"] + st["shadow_rays"]
         flops = algorithmic_flops(flat["shape_type"], args.height * args.width, st["color_rays"], st["shadow_rays"])
         peak = FP64_VECTOR_PEAK_TFLOPS if prec == rta.F64 else FP32_VECTOR_PEAK_TFLOPS
-        culled = bool(scene.features()["bounding_sphere_tests"])
         res["%s_%s" % (name, precision)] = {
             "frame_ms": ms, "Mrays_per_s": rays / (ms * 1e-3) / 1e6, "rays": rays, "objects": int(len(flat["shape_type"])),
             "rays_per_level": st["rays_per_level"], "launches": st["n_launches"], "chunks": st["n_chunks"],
@@ -479,8 +491,16 @@ def extra_scenes(rta, ctx, args):
             "valu_TFLOPs": flops / (ms * 1e-3) / 1e12,
             "roofline_frac": None if culled else flops / (ms * 1e-3) / 1e12 / peak,
             "bounding_sphere_tests": culled,
+            # device memory the secondary-ray queues of this frame hold
+            "queue_GB": queue_gb,
         }
-        scene.close()
+        if name == "glass":
+            # the library's default for a frame this size is to size each level's queue from the lengths of
+            # the level before (a host round trip per level); the same frame with every queue sized for the
+            # worst case on the host, which is what a caller who passes a stream of its own gets
+            ms_w, _, _, _, gb_w = frame_time(name, precision, kw, never)
+            res["%s_%s" % (name, precision)]["worst_case_queues"] = {"frame_ms": ms_w, "queue_GB": gb_w,
+                                                                      "Mrays_per_s": rays / (ms_w * 1e-3) / 1e6}
     if not args.no_cpu_baseline:
         # the oracle beside the other two scenes as well (short samples: a few seconds of CPU work each)
         for name in ("glass", "random"):

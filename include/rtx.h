@@ -141,6 +141,18 @@ int rtx_context_set_debug_queue_divisor(rtx_context *ctx, uint32_t divisor);
 /* Upper bound in bytes for the secondary-ray queues of one render call (default: a sixth of
  * the device memory, at least 8 GiB); frames that could exceed it are rendered in row chunks. */
 int rtx_context_set_workspace_limit(rtx_context *ctx, size_t bytes);
+/* Secondary-ray queues are sized on the host for the worst case, which doubles with every level in
+ * a scene that both reflects and refracts (World::reflected_color and World::refracted_color,
+ * src/scenes/world.rs:160-190, both recurse): about 26 GB for a 4K frame of depth 5 whose rays
+ * would fit 2 GB.  A call that returns a finished frame (no stream of the caller's, or host
+ * output, or stats) and whose worst case exceeds `worst_case_bytes_above` reads the lengths of
+ * each level's queues back before launching it and sizes the next level for what those rays can
+ * produce at most: a host round trip per level (about 11 us) instead of the memory.  Default 8 GiB;
+ * 0 = whenever the scene allows it, SIZE_MAX = never.  Scenes with bounding-sphere tests and
+ * scenes whose rays cannot branch keep the plain sizing.  No counterpart in the reference. */
+int rtx_context_set_measured_queues(rtx_context *ctx, size_t worst_case_bytes_above);
+/* Device memory the context's render calls currently hold for secondary-ray queues. */
+int rtx_context_queue_bytes(rtx_context *ctx, size_t *bytes);
 
 /* Scenes uploaded afterwards test a ray against an object's bounding sphere before the exact
  * intersection when they hold at least this many bounded objects (spheres, cubes, cylinders with

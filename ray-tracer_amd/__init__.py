@@ -115,6 +115,8 @@ rtx_context_destroy = _bind("rtx_context_destroy", None, [_vp])
 rtx_context_synchronize = _bind("rtx_context_synchronize", C.c_int, [_vp])
 rtx_context_set_debug_queue_divisor = _bind("rtx_context_set_debug_queue_divisor", C.c_int, [_vp, C.c_uint32])
 rtx_context_set_workspace_limit = _bind("rtx_context_set_workspace_limit", C.c_int, [_vp, C.c_size_t])
+rtx_context_set_measured_queues = _bind("rtx_context_set_measured_queues", C.c_int, [_vp, C.c_size_t])
+rtx_context_queue_bytes = _bind("rtx_context_queue_bytes", C.c_int, [_vp, C.POINTER(C.c_size_t)])
 rtx_context_set_cull_threshold = _bind("rtx_context_set_cull_threshold", C.c_int, [_vp, C.c_uint32])
 rtx_scene_upload = _bind("rtx_scene_upload", C.c_int, [_vp, C.POINTER(SceneDesc), C.POINTER(_vp)])
 rtx_scene_destroy = _bind("rtx_scene_destroy", None, [_vp])
@@ -161,7 +163,7 @@ rtx_device_info = _bind("rtx_device_info", C.c_int, [_vp, C.c_char_p, C.c_size_t
 # every symbol include/rtx.h declares
 RTX_SYMBOLS = ["rtx_last_error", "rtx_context_create", "rtx_context_destroy", "rtx_context_synchronize",
                "rtx_context_set_debug_queue_divisor", "rtx_context_set_workspace_limit",
-               "rtx_context_set_cull_threshold",
+               "rtx_context_set_cull_threshold", "rtx_context_set_measured_queues", "rtx_context_queue_bytes",
                "rtx_scene_upload", "rtx_scene_destroy", "rtx_scene_features", "rtx_render", "rtx_render_8bit", "rtx_render_device", "rtx_part_rows", "rtx_render_part_device", "rtx_render_device_noalloc", "rtx_trace_rays",
                "rtx_probe_rays", "rtx_selfcheck_division", "rtx_selfcheck_pow", "rtx_generate_rays", "rtx_quantize_u8_device", "rtx_device_info", "rtx_multi_last_error", "rtx_multi_create",
                "rtx_multi_destroy", "rtx_multi_device_count", "rtx_multi_scene_upload", "rtx_multi_scene_destroy", "rtx_multi_render"]
@@ -284,6 +286,14 @@ class Context:
 
     def set_workspace_limit(self, nbytes):
         _check(rtx_context_set_workspace_limit(self.h, nbytes))
+
+    def set_measured_queues(self, worst_case_bytes_above):
+        _check(rtx_context_set_measured_queues(self.h, worst_case_bytes_above))
+
+    def queue_bytes(self):
+        n = C.c_size_t()
+        _check(rtx_context_queue_bytes(self.h, C.byref(n)))
+        return n.value
 
     def set_cull_threshold(self, min_bounded_objects):
         _check(rtx_context_set_cull_threshold(self.h, min_bounded_objects))

@@ -79,6 +79,7 @@ RT_DEV void entry_take(const QueueChunk *lds, uint32_t wave, uint32_t lane, bool
 //      computes.
 #ifdef RTX_PHASE_CLOCK
 static __device__ unsigned int g_slow_flag;
+static __device__ unsigned long long g_slow_threshold = 3000000ull;  // cycles of a round above which its rays are kept
 static __device__ double g_slow_rays[64 * 8];
 #endif
 // COLD_LDS: the launch comes with cold_lds_bytes() of dynamic LDS and the scene has at most
@@ -193,11 +194,11 @@ k_bounce(BounceArgs<R> args_in_kernarg_segment)
                 atomicMax(&g_phase[13], took);
                 if (took > 100000ull) atomicAdd(&g_phase[12], 1ull);
             }
-            // the rays of the first wave whose round took over 3 million cycles
+            // the rays of the first wave whose round took over g_slow_threshold cycles
             unsigned int claimed = 1u;
-            if (took > 3000000ull && phase_leader()) claimed = atomicCAS(&g_slow_flag, 0u, 1u);
+            if (took > g_slow_threshold && phase_leader()) claimed = atomicCAS(&g_slow_flag, 0u, 1u);
             claimed = __shfl(claimed, (int)(__ffsll((long long)__ballot(1)) - 1));
-            if (took > 3000000ull && claimed == 0u) {
+            if (took > g_slow_threshold && claimed == 0u) {
                 double *o = g_slow_rays + (threadIdx.x & 63u) * 8;
                 o[0] = dbg_o.x; o[1] = dbg_o.y; o[2] = dbg_o.z; o[3] = dbg_d.x; o[4] = dbg_d.y; o[5] = dbg_d.z;
                 o[6] = valid ? 1.0 : 0.0; o[7] = (double)took;
@@ -297,11 +298,11 @@ __global__ void __launch_bounds__(kRayBlock<R>) k_split_shade(BounceArgs<R> A, c
 template <typename R>
 hipError_t launch_bounce(uint32_t sf, hipStream_t stream, const SceneDev<R> &scene, const QueueDev<R> &in_q,
                              const QueueDev<R> &out_q, uint32_t remaining, uint32_t level, R *fb, StatShard *stats,
-                             uint32_t resident_blocks)
+                             uint32_t resident_blocks, uint32_t longest)
 {
     if ((sf & (SF_REFLECTIVE | SF_TRANSPARENT)) == 0 || in_q.cap_sub == 0) return hipSuccess;  // nothing can be queued
     const uint32_t n_sub = in_q.sub_mask + 1;
-    const uint32_t worst = (in_q.cap_sub + kRayBlock<R> - 1) / kRayBlock<R>;
+    const uint32_t worst = ((longest ? longest : in_q.cap_sub) + kRayBlock<R> - 1) / kRayBlock<R>;
     const uint32_t share = resident_blocks / n_sub > 0 ? resident_blocks / n_sub : 1u;
     const dim3 grid(worst < share ? worst : share, n_sub);
     const BounceArgs<R> args = { scene, in_q, out_q, remaining, level, fb, stats };

@@ -71,20 +71,23 @@ struct Launch {
 
 // One recursion level below the primary rays: consume in_q, add weight * lighting into fb, queue
 // the next level.  The launch has about resident_blocks workgroups (what the chip holds at
-// once), shared out evenly among the sub-queues; they loop over the rays that exist.
+// once), shared out evenly among the sub-queues; they loop over the rays that exist.  `longest`:
+// the length of the longest input sub-queue when the caller knows it (0: only its capacity is known).
 template <typename R>
 hipError_t launch_bounce(uint32_t sf, hipStream_t stream, const SceneDev<R> &scene, const QueueDev<R> &in_q,
                          const QueueDev<R> &out_q, uint32_t remaining, uint32_t level, R *fb, StatShard *stats,
-                         uint32_t resident_blocks);
+                         uint32_t resident_blocks, uint32_t longest = 0);
 extern template hipError_t launch_bounce<double>(uint32_t, hipStream_t, const SceneDev<double> &, const QueueDev<double> &,
-                                                 const QueueDev<double> &, uint32_t, uint32_t, double *, StatShard *, uint32_t);
+                                                 const QueueDev<double> &, uint32_t, uint32_t, double *, StatShard *, uint32_t, uint32_t);
 extern template hipError_t launch_bounce<float>(uint32_t, hipStream_t, const SceneDev<float> &, const QueueDev<float> &,
-                                                const QueueDev<float> &, uint32_t, uint32_t, float *, StatShard *, uint32_t);
+                                                const QueueDev<float> &, uint32_t, uint32_t, float *, StatShard *, uint32_t, uint32_t);
 
 // Size of the file-scope device array behind rtx_render_device_noalloc (scratch.hip), and its
 // device address on the current device.
 constexpr size_t kScratchBytes = (size_t)256 << 20;
 hipError_t scratch_address(void **ptr, size_t *bytes);
+// sub-queue lengths into host memory the device can write, then a sequence number (scratch.hip)
+hipError_t launch_publish_counts(hipStream_t stream, const uint32_t *counts, uint32_t n_sub, uint32_t stride, uint32_t *host, uint32_t seq);
 
 // f64 only: intermediate results of one color_at node per ray.
 hipError_t launch_probe(uint32_t sf, uint32_t grid, hipStream_t stream, const SceneDev<double> &scene,

@@ -25,6 +25,8 @@ def main():
     ctx = rta.Context(0)
     if os.environ.get("RTX_WORKSPACE_GIB"):
         ctx.set_workspace_limit(int(float(os.environ["RTX_WORKSPACE_GIB"]) * (1 << 30)))
+    if os.environ.get("RTX_MEASURED_ABOVE"):  # worst-case queue bytes above which frames are sized level by level
+        ctx.set_measured_queues(int(os.environ["RTX_MEASURED_ABOVE"]))
     for case in cases:
         name, precision = case.split(":")
         world, cam = scenes.SCENES[name](rta.api, hsize=W, vsize=H)
@@ -43,9 +45,9 @@ def main():
             prim.append(st["primary_kernel_ms"])
         rays = st["color_rays"] + st["shadow_rays"]
         ms = float(np.median(times[2:]))
-        print("%-18s %s frame %8.4f ms (min %8.4f) primary %8.4f  chunks %d launches %d  %9.0f Mrays/s  checksum %.12g" %
+        print("%-18s %s frame %8.4f ms (min %8.4f) primary %8.4f  chunks %d launches %d  %9.0f Mrays/s  queues %.2f GB  checksum %.12g" %
               (name, precision, ms, min(times), float(np.median(prim[2:])), st["n_chunks"], st["n_launches"], rays / ms / 1e3,
-               float(tile.double().sum())), flush=True)
+               ctx.queue_bytes() / 1e9, float(tile.double().sum())), flush=True)
         scene.close()
 
 
