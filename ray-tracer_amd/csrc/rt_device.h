@@ -234,6 +234,19 @@ template <typename R, typename M> RT_DEV V3<R> xform_vector(M m, V3<R> v)
              (m[8] * v.x + m[9] * v.y) + m[10] * v.z };
 }
 
+// The same two products for a matrix whose upper-left 3x3 is diagonal (SLOT_DIAGONAL).  The
+// general expressions add m * y with m = +-0 to the diagonal term, which leaves it as it is
+// (x + 0 == x; only a result that is itself zero can come out with the other sign, and no
+// intersection routine divides by, or takes the sign of, such a coordinate), so these are the
+// reference's values for every finite ray at 6 + 3 operations instead of 18 + 15.  A ray with an
+// infinite or NaN component is the exception (0 * inf is NaN there and not here): the reference
+// panics on such a ray (the sort of its intersections unwraps a partial_cmp, world.rs:105).
+template <typename R, typename M> RT_DEV V3<R> diag_point(M m, V3<R> p)
+{
+    return { m[0] * p.x + m[3], m[5] * p.y + m[7], m[10] * p.z + m[11] };
+}
+template <typename R, typename M> RT_DEV V3<R> diag_vector(M m, V3<R> v) { return { m[0] * v.x, m[5] * v.y, m[10] * v.z }; }
+
 // ---- ray/object intersection in object space -----------------------------------------
 // Each routine calls emit(t) once per intersection, in the order the reference pushes them;
 // emit(t, ok) stands for `if (ok) emit(t)` where the condition is cheap (the callers fold it into
@@ -788,36 +801,52 @@ RT_DEV void walk_scene(const SceneDev<R> &S, V3<R> ro, V3<R> rd, const Keep &kee
 #else
 #define RTX_LDS_ARG(f)
 #endif
+    // the ray in the space of the object at `slot` (wave-uniform branch: the flag is a scalar)
+    auto into_object = [&](const R *m, uint32_t slot, V3<R> &o, V3<R> &d) {
+        if (ro_load(S.slot_flags + slot) & SLOT_DIAGONAL) {
+            o = diag_point(m, ro);
+            d = diag_vector(m, rd);
+        } else {
+            o = xform_point(m, ro);
+            d = xform_vector(m, rd);
+        }
+    };
     walk_table(S.sph, S.n_sph, slot0, S.cl_off[SH_SPHERE], S.grp_off[SH_SPHERE], keep, [&](const XformRec<R> &rec, uint32_t slot) {
-        const V3<R> o = xform_point(rec.m, ro);
-        const V3<R> d = xform_vector(rec.m, rd);
+        V3<R> o, d;
+        into_object(rec.m, slot, o, d);
         per(slot, [&](auto &&emit) { isect_sphere(o, d, sphere_c(o), emit); });
     } RTX_LDS_ARG(sph));
     slot0 += S.n_sph;
     walk_table(S.pln, S.n_pln, slot0, 0u, 0u, KeepAll(), [&](const PlaneRec<R> &rec, uint32_t slot) {
         // only the y row of the object-space ray is read by planes.rs:11-17
-        const R oy = ((rec.m[0] * ro.x + rec.m[1] * ro.y) + rec.m[2] * ro.z) + rec.m[3];
-        const R dy = (rec.m[0] * rd.x + rec.m[1] * rd.y) + rec.m[2] * rd.z;
+        R oy, dy;
+        if (ro_load(S.slot_flags + slot) & SLOT_DIAGONAL) {
+            oy = rec.m[1] * ro.y + rec.m[3];
+            dy = rec.m[1] * rd.y;
+        } else {
+            oy = ((rec.m[0] * ro.x + rec.m[1] * ro.y) + rec.m[2] * ro.z) + rec.m[3];
+            dy = (rec.m[0] * rd.x + rec.m[1] * rd.y) + rec.m[2] * rd.z;
+        }
         per(slot, [&](auto &&emit) { isect_plane(-oy, dy, emit); });
     } RTX_LDS_ARG(pln));
     slot0 += S.n_pln;
     walk_table(S.cub, S.n_cub, slot0, S.cl_off[SH_CUBE], S.grp_off[SH_CUBE], keep, [&](const XformRec<R> &rec, uint32_t slot) {
-        const V3<R> o = xform_point(rec.m, ro);
-        const V3<R> d = xform_vector(rec.m, rd);
+        V3<R> o, d;
+        into_object(rec.m, slot, o, d);
         const V3<R> lo = { R(-1) - o.x, R(-1) - o.y, R(-1) - o.z };
         const V3<R> hi = { R(1) - o.x, R(1) - o.y, R(1) - o.z };
         per(slot, [&](auto &&emit) { isect_cube(lo, hi, d, emit); });
     } RTX_LDS_ARG(cub));
     slot0 += S.n_cub;
     walk_table(S.cyl, S.n_cyl, slot0, S.cl_off[SH_CYLINDER], S.grp_off[SH_CYLINDER], keep, [&](const CappedRec<R> &rec, uint32_t slot) {
-        const V3<R> o = xform_point(rec.m, ro);
-        const V3<R> d = xform_vector(rec.m, rd);
+        V3<R> o, d;
+        into_object(rec.m, slot, o, d);
         per(slot, [&](auto &&emit) { isect_cylinder(o, twice(o), cylinder_c(o), d, rec.ymin, rec.ymax, rec.closed != 0, emit); });
     } RTX_LDS_ARG(cyl));
     slot0 += S.n_cyl;
     walk_table(S.con, S.n_con, slot0, 0u, 0u, KeepAll(), [&](const CappedRec<R> &rec, uint32_t slot) {
-        const V3<R> o = xform_point(rec.m, ro);
-        const V3<R> d = xform_vector(rec.m, rd);
+        V3<R> o, d;
+        into_object(rec.m, slot, o, d);
         per(slot, [&](auto &&emit) { isect_cone(o, twice(o), cone_c(o), d, rec.ymin, rec.ymax, rec.closed != 0, emit); });
     } RTX_LDS_ARG(con));
 #undef RTX_LDS_ARG
@@ -833,23 +862,29 @@ template <typename R> RT_DEV V3<R> xform_vector9(const R *m, V3<R> v)
              (m[3] * v.x + m[4] * v.y) + m[5] * v.z,
              (m[6] * v.x + m[7] * v.y) + m[8] * v.z };
 }
+// a direction into the space of the object at `slot` (diag_vector when its 3x3 is diagonal)
+template <typename R> RT_DEV V3<R> primary_direction(const SceneDev<R> &S, uint32_t slot, const R *m, V3<R> v)
+{
+    if (ro_load(S.slot_flags + slot) & SLOT_DIAGONAL) return { m[0] * v.x, m[4] * v.y, m[8] * v.z };
+    return xform_vector9(m, v);
+}
 template <typename R, bool CHAIN, typename Keep, typename Per>
 RT_DEV void walk_scene_primary(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> ro, V3<R> rd, const Keep &keep, Per &&per)
 {
     uint32_t slot0 = 0;
     walk_table(P.sph, P.n_sph, slot0, S.cl_off[SH_SPHERE], S.grp_off[SH_SPHERE], keep, [&](const PrimSphereRec<R> &rec, uint32_t slot) {
         const V3<R> o = { rec.o[0], rec.o[1], rec.o[2] };
-        const V3<R> d = xform_vector9(rec.m, rd);
+        const V3<R> d = primary_direction(S, slot, rec.m, rd);
         per(slot, [&](auto &&emit) { isect_sphere(o, d, rec.c, emit); });
     });
     slot0 += P.n_sph;
     walk_table(P.pln, P.n_pln, slot0, 0u, 0u, KeepAll(), [&](const PrimPlaneRec<R> &rec, uint32_t slot) {
-        const R dy = (rec.m[0] * rd.x + rec.m[1] * rd.y) + rec.m[2] * rd.z;
+        const R dy = (ro_load(S.slot_flags + slot) & SLOT_DIAGONAL) ? rec.m[1] * rd.y : (rec.m[0] * rd.x + rec.m[1] * rd.y) + rec.m[2] * rd.z;
         per(slot, [&](auto &&emit) { isect_plane(rec.neg_oy, dy, emit); });
     });
     slot0 += P.n_pln;
     walk_table(P.cub, P.n_cub, slot0, S.cl_off[SH_CUBE], S.grp_off[SH_CUBE], keep, [&](const PrimCubeRec<R> &rec, uint32_t slot) {
-        const V3<R> d = xform_vector9(rec.m, rd);
+        const V3<R> d = primary_direction(S, slot, rec.m, rd);
         const V3<R> lo = { rec.lo[0], rec.lo[1], rec.lo[2] };
         const V3<R> hi = { rec.hi[0], rec.hi[1], rec.hi[2] };
         per(slot, [&](auto &&emit) { isect_cube(lo, hi, d, emit); });
@@ -858,14 +893,14 @@ RT_DEV void walk_scene_primary(const SceneDev<R> &S, const PrimScene<R> &P, V3<R
     walk_table(P.cyl, P.n_cyl, slot0, S.cl_off[SH_CYLINDER], S.grp_off[SH_CYLINDER], keep, [&](const PrimCappedRec<R> &rec, uint32_t slot) {
         const V3<R> o = { rec.o[0], rec.o[1], rec.o[2] };
         const V3<R> o2 = { rec.o2[0], rec.o2[1], rec.o2[2] };
-        const V3<R> d = xform_vector9(rec.m, rd);
+        const V3<R> d = primary_direction(S, slot, rec.m, rd);
         per(slot, [&](auto &&emit) { isect_cylinder(o, o2, rec.c, d, rec.ymin, rec.ymax, rec.closed != 0, emit); });
     });
     slot0 += P.n_cyl;
     walk_table(P.con, P.n_con, slot0, 0u, 0u, KeepAll(), [&](const PrimCappedRec<R> &rec, uint32_t slot) {
         const V3<R> o = { rec.o[0], rec.o[1], rec.o[2] };
         const V3<R> o2 = { rec.o2[0], rec.o2[1], rec.o2[2] };
-        const V3<R> d = xform_vector9(rec.m, rd);
+        const V3<R> d = primary_direction(S, slot, rec.m, rd);
         per(slot, [&](auto &&emit) { isect_cone(o, o2, rec.c, d, rec.ymin, rec.ymax, rec.closed != 0, emit); });
     });
     if constexpr (CHAIN) walk_chained(S, ro, rd, per);

@@ -11,6 +11,10 @@ enum : uint32_t { SH_SPHERE = 0, SH_PLANE = 1, SH_CUBE = 2, SH_CYLINDER = 3, SH_
 enum : uint32_t { PT_SOLID = 0, PT_STRIPE = 1, PT_GRADIENT = 2, PT_RING = 3, PT_CHECKER = 4, PT_TEST = 5 };
 
 enum : uint32_t { OF_CLOSED = 1u, OF_CASTS_SHADOW = 2u, OF_CONTAINER = 4u };
+// Per slot.  SLOT_DIAGONAL: the upper-left 3x3 of the object's inverse transform has zeros off its
+// diagonal (an object that was only translated and scaled, the common case): taking a ray into
+// object space is then a multiply per component, plus an add for a point.
+enum : uint32_t { SLOT_DIAGONAL = 1u };
 
 // Scene-wide feature bits; the kernels are compiled once per combination that changes code.
 enum : uint32_t {
@@ -155,6 +159,7 @@ struct SceneDev {
     uint32_t cl_off[5];
     uint32_t grp_off[5];
     const uint32_t *slot_obj;  // slot -> index in World.objects (the tie-break order among equal t)
+    const uint32_t *slot_flags;  // by slot: SLOT_* bits
     const ColdRec<R> *cold;    // by index in World.objects
     uint32_t n_sph, n_pln, n_cub, n_cyl, n_con;
     uint32_t n;

@@ -305,6 +305,7 @@ struct Tables {
     std::vector<BoundRec<R>> bnd, cl, grp;
     uint32_t cl_off[5] = { 0, 0, 0, 0, 0 }, grp_off[5] = { 0, 0, 0, 0, 0 };
     std::vector<uint32_t> slot_obj;
+    std::vector<uint32_t> slot_flags;
     std::vector<ColdRec<R>> cold;
     // sphere around every bounded object (r = +inf: none, or no bounding-sphere tests)
     double world_c[3] = { 0, 0, 0 }, world_r = std::numeric_limits<double>::infinity();
@@ -550,6 +551,12 @@ void fill_tables(const rtx_scene_desc *d, const std::vector<uint8_t> &container,
         for (uint32_t i : order) {
             const double *inv = d->inverse + (size_t)i * 16;
             t.slot_obj.push_back(i);
+            // an inverse whose upper-left 3x3 is diagonal: the kernels take a ray into this object's space with
+            // a multiply per component (zeros of either sign count; a plane reads row 1 only)
+            const bool diagonal = shape == RTX_PLANE ? (inv[4] == 0.0 && inv[6] == 0.0)
+                                                     : (inv[1] == 0.0 && inv[2] == 0.0 && inv[4] == 0.0 && inv[6] == 0.0 &&
+                                                        inv[8] == 0.0 && inv[9] == 0.0);
+            t.slot_flags.push_back(diagonal ? SLOT_DIAGONAL : 0u);
             t.bnd.push_back(store(bounds[i].c, bounds[i].r));
             if (shape == RTX_SPHERE || shape == RTX_CUBE) {
                 XformRec<R> r;
@@ -587,6 +594,7 @@ void fill_tables(const rtx_scene_desc *d, const std::vector<uint8_t> &container,
         r.depth = depth;
         t.chn.push_back(r);
         t.slot_obj.push_back(i);
+        t.slot_flags.push_back(0u);
         t.bnd.push_back(store(bounds[i].c, bounds[i].r));
     }
     // The world sphere: around every object that has a finite sphere, with room for the inflation above.
@@ -617,10 +625,11 @@ int upload_tables(const Tables<R> &t, uint32_t sf, const rtx_scene_desc *d, void
     const size_t b_sph = pad(t.sph.size() * sizeof(XformRec<R>)), b_pln = pad(t.pln.size() * sizeof(PlaneRec<R>)),
                  b_cub = pad(t.cub.size() * sizeof(XformRec<R>)), b_cyl = pad(t.cyl.size() * sizeof(CappedRec<R>)),
                  b_con = pad(t.con.size() * sizeof(CappedRec<R>)), b_slot = pad(t.slot_obj.size() * sizeof(uint32_t)),
+                 b_flags = pad(t.slot_flags.size() * sizeof(uint32_t)),
                  b_cold = pad(t.cold.size() * sizeof(ColdRec<R>)), b_bnd = pad(t.bnd.size() * sizeof(BoundRec<R>)),
                  b_cl = pad(t.cl.size() * sizeof(BoundRec<R>)), b_grp = pad(t.grp.size() * sizeof(BoundRec<R>)),
                  b_chn = pad(t.chn.size() * sizeof(ChainRec<R>));
-    const size_t total = b_sph + b_pln + b_cub + b_cyl + b_con + b_slot + b_cold + b_bnd + b_cl + b_grp + b_chn + 256;
+    const size_t total = b_sph + b_pln + b_cub + b_cyl + b_con + b_slot + b_flags + b_cold + b_bnd + b_cl + b_grp + b_chn + 256;
     std::vector<char> host(total, 0);
     size_t off = 0;
     auto put = [&](const void *src, size_t bytes, size_t padded) {
@@ -635,6 +644,7 @@ int upload_tables(const Tables<R> &t, uint32_t sf, const rtx_scene_desc *d, void
     const size_t o_cyl = put(t.cyl.data(), t.cyl.size() * sizeof(CappedRec<R>), b_cyl);
     const size_t o_con = put(t.con.data(), t.con.size() * sizeof(CappedRec<R>), b_con);
     const size_t o_slot = put(t.slot_obj.data(), t.slot_obj.size() * sizeof(uint32_t), b_slot);
+    const size_t o_flags = put(t.slot_flags.data(), t.slot_flags.size() * sizeof(uint32_t), b_flags);
     const size_t o_cold = put(t.cold.data(), t.cold.size() * sizeof(ColdRec<R>), b_cold);
     const size_t o_bnd = put(t.bnd.data(), t.bnd.size() * sizeof(BoundRec<R>), b_bnd);
     const size_t o_cl = put(t.cl.data(), t.cl.size() * sizeof(BoundRec<R>), b_cl);
@@ -650,6 +660,7 @@ int upload_tables(const Tables<R> &t, uint32_t sf, const rtx_scene_desc *d, void
     dev->cyl = (const CappedRec<R> *)(base + o_cyl);
     dev->con = (const CappedRec<R> *)(base + o_con);
     dev->slot_obj = (const uint32_t *)(base + o_slot);
+    dev->slot_flags = (const uint32_t *)(base + o_flags);
     dev->cold = (const ColdRec<R> *)(base + o_cold);
     dev->bnd = (const BoundRec<R> *)(base + o_bnd);
     dev->cl = (const BoundRec<R> *)(base + o_cl);
