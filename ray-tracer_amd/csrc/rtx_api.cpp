@@ -127,7 +127,8 @@ struct rtx_context {
     size_t workspace_limit = (size_t)8 << 30;
     uint32_t cull_min_objects = 16;  // scenes with at least this many bounded objects get the bounding-sphere tests
     uint32_t blocks_per_cu = 8;
-    uint32_t bounce_blocks = 4096;   // workgroups of one bounce launch: about what the chip holds at once
+    uint32_t bounce_blocks = 7680;   // workgroups of one bounce launch (set from the device's size at creation)
+    uint32_t bounce_blocks_cull = 0xffffffffu;  // the same for scenes with bounding-sphere tests: one per piece the queue can hold
     void *scratch = nullptr;         // this device's copy of the file-scope array of scratch.hip
     size_t scratch_bytes = 0;
     uint32_t *overflow_host = nullptr;  // pinned word the kernels set when a ray queue overflows
@@ -1090,7 +1091,7 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Workspace &ws, hipEv
             // its length leave at once; measured 6.9 against 7.4 ms on the 10k-object frame), the
             // others as many workgroups as the chip holds at once.
             HIP_TRY(launch_bounce<R>(scene->sf, stream, S, queue_at(L), queue_at(L + 1), max_depth - L, L, fb, ws.shards,
-                                     (scene->sf & SF_CULL) ? 0xffffffffu : ctx->bounce_blocks));
+                                     (scene->sf & SF_CULL) ? ctx->bounce_blocks_cull : ctx->bounce_blocks));
             ++launches;
         }
         done += cam ? units * W : units;
@@ -1360,10 +1361,19 @@ int rtx_context_create(int device_id, rtx_context **out)
         int v = std::atoi(e);
         if (v >= 0) ctx->cull_min_objects = (uint32_t)v;
     }
-    ctx->bounce_blocks = (uint32_t)ctx->cu_count * 16u;
+    // Workgroups of a bounce launch: each loops over its share of a sub-queue's rays.  The chip holds about
+    // 10 of them per CU at once (f64: 2 waves of 85 registers each); three times that many, shorter ones
+    // keep it filled to the end of the launch: pieces of 128 rays differ several-fold in what they cost
+    // (4K glass frame: 2.04 ms with 8 per CU, 1.93 with 16, 1.84 with 30, 1.81-1.88 with 50-100; one per
+    // piece, 2.57).  Handing the pieces out by ticket instead was slower than this fixed split.
+    ctx->bounce_blocks = (uint32_t)ctx->cu_count * 30u;
     if (const char *e = std::getenv("RTX_BOUNCE_BLOCKS")) {
         int v = std::atoi(e);
         if (v >= 1) ctx->bounce_blocks = (uint32_t)v;
+    }
+    if (const char *e = std::getenv("RTX_BOUNCE_BLOCKS_CULL")) {
+        int v = std::atoi(e);
+        if (v >= 1) ctx->bounce_blocks_cull = (uint32_t)v;
     }
     if (const char *e = std::getenv("RTX_BLOCKS_PER_CU")) {
         int v = std::atoi(e);
