@@ -102,6 +102,10 @@ k_bounce(BounceArgs<R> args_in_kernarg_segment)
     const uint32_t sub_in = blockIdx.y;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t step = gridDim.x * kRayBlock<R>;
+    // one ray per wave for short levels: scenes with the sphere hierarchy whose rays carry no container
+    // bookkeeping (that is kept per lane and not joined across lanes)
+    constexpr bool kWide = (SF & SF_CULL) != 0 && (SF & SF_TRANSPARENT) == 0 && !kLaneWalk;
+    constexpr uint32_t kWideRays = 65536u;
 #ifdef RTX_LDS_TABLES
     if constexpr ((SF & SF_CULL) == 0) stage_tables<R>(args_in_kernarg_segment.S);
 #endif
@@ -136,7 +140,13 @@ k_bounce(BounceArgs<R> args_in_kernarg_segment)
             const uint32_t budget = kSpreadLanes / gridDim.y;  // lanes per sub-queue when the chip is lightly loaded
             const uint64_t room = ((uint64_t)A.in_q.cap_sub + kRayBlock<R> - 1) / kRayBlock<R> * kRayBlock<R>;
             while (spread < 64u && (uint64_t)n * (spread * 2u) <= budget && (uint64_t)n * (spread * 2u) <= room) spread *= 2u;
+            // A level of at most kWideRays rays gets a wave per ray, whose 64 lanes walk the sphere hierarchy
+            // side by side (wide_walk_table): 64 waves per SIMD at most, each some 30 steps long.
+            if constexpr (kWide) {
+                if ((uint64_t)n * gridDim.y <= kWideRays && (uint64_t)n * 64u <= room) spread = 64u;
+            }
         }
+        const bool wide = kWide && spread == 64u;  // wave-uniform
         const uint32_t total = n * spread;  // lane slots of this sub-queue
         if (base >= total) break;
         auto slot_of = [&](uint32_t block_base, uint32_t &k) {
@@ -169,8 +179,33 @@ k_bounce(BounceArgs<R> args_in_kernarg_segment)
 #ifdef RTX_PHASE_CLOCK
         const V3<R> dbg_o = ro, dbg_d = rd;
 #endif
-        if (valid) {
-            nd = trace_node<R, SF, false, kLaneWalk && (SF & SF_CULL) != 0, COLD_LDS>(A.S, nullptr, ro, rd, A.remaining, [&](const Node<R> &c) {
+        bool done = false;
+        if constexpr (kWide) {
+            if (wide) {
+                // the wave's one ray sits in lane 0 (the lane slots of a ray start at a multiple of 64):
+                // every lane gets it, every lane computes the same node, lane 0 alone acts on it
+                auto all = [](R v) {
+                    if constexpr (sizeof(R) == 8) {
+                        const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+                        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+                        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
+                        return __builtin_bit_cast(R, ((unsigned long long)hi << 32) | lo);
+                    } else {
+                        return __builtin_bit_cast(R, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+                    }
+                };
+                if (__ballot(valid) != 0ull) {
+                    const V3<R> o = { all(ro.x), all(ro.y), all(ro.z) }, d = { all(rd.x), all(rd.y), all(rd.z) };
+                    nd = trace_node<R, SF, false, WALK_WIDE, COLD_LDS>(A.S, nullptr, o, d, A.remaining, [&](const Node<R> &c) {
+                        queue_push2(A.out_q, sub, c.has_reflect && lane == 0u, c.over_point, c.reflectv, w * c.reflect_factor,
+                                    c.has_refract && lane == 0u, c.under_point, c.refract_dir, w * c.refract_factor, px_index);
+                    });
+                }
+                done = true;
+            }
+        }
+        if (!done && valid) {
+            nd = trace_node<R, SF, false, (kLaneWalk && (SF & SF_CULL) != 0) ? WALK_LANE : WALK_WAVE, COLD_LDS>(A.S, nullptr, ro, rd, A.remaining, [&](const Node<R> &c) {
                 queue_push2(A.out_q, sub, c.has_reflect, c.over_point, c.reflectv, w * c.reflect_factor, c.has_refract,
                             c.under_point, c.refract_dir, w * c.refract_factor, px_index);
             });
@@ -280,7 +315,7 @@ __global__ void __launch_bounds__(kRayBlock<R>) k_split_shade(BounceArgs<R> A, c
         Hit<R> h;
         h.t = r.t; h.slot = r.slot; h.obj = r.obj; h.top1 = r.top1; h.top2 = r.top2; h.hit_open = r.open != 0u;
         h.top1_t = h.top2_t = R(0);
-        nd = shade_node<R, SF, false, false, false>(A.S, ro, rd, A.remaining, h, [&](const Node<R> &c) {
+        nd = shade_node<R, SF, false, WALK_WAVE, false>(A.S, ro, rd, A.remaining, h, [&](const Node<R> &c) {
             queue_push2(A.out_q, sub, c.has_reflect, c.over_point, c.reflectv, weight * c.reflect_factor, c.has_refract, c.under_point,
                         c.refract_dir, weight * c.refract_factor, pixel);
         });

@@ -717,6 +717,81 @@ RT_DEV void lane_walk_table(const Rec *recs, uint32_t n, uint32_t slot0, uint32_
     }
 }
 
+// The walk for a wave that holds ONE ray (the deep recursion levels of a scene with thousands of
+// objects hold a few thousand rays for a chip of 65 000 lanes): the ray is the same in every lane
+// and the 64 lanes test 64 spheres of a level at once -- every group of a table, then the 16
+// clusters of up to four groups that may be hit, then the 16 members of up to four such
+// clusters, each lane finishing with the exact intersection of the one object it is left with.
+// Some 30 steps where the wave-uniform walk with one lane in use takes 500 dependent fetches.
+// Every lane keeps the closest hit among the objects it tested itself (closest_hit_with joins
+// them); what a finished batch found shortens the reach of the next (wave_best).
+// Same tests, same spheres, same exact intersections as the other walks; the order in which
+// objects are met differs, and ties between equal t are settled by World index, not by order.
+enum : int { WALK_WAVE = 0, WALK_LANE = 1, WALK_WIDE = 2 };
+template <typename T> RT_DEV T wave_min(T v)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        const T other = __shfl_xor(v, off);
+        v = other < v ? other : v;
+    }
+    return v;
+}
+// the positions of the (up to) four lowest set bits of a wave-uniform mask, which loses them
+RT_DEV uint32_t pop_four(unsigned long long &mask, uint32_t pos[4])
+{
+    uint32_t count = 0;
+    for (int j = 0; j < 4; ++j) {
+        pos[j] = 0u;
+        if (mask != 0ull) {
+            pos[j] = (uint32_t)__builtin_ctzll(mask);
+            mask &= mask - 1ull;
+            ++count;
+        }
+    }
+    return count;
+}
+template <typename R, bool LINE, typename Rec, typename Body>
+RT_DEV void wide_walk_table(const Rec *recs, uint32_t n, uint32_t slot0, uint32_t cluster0, uint32_t group0,
+                            const SphereCull<R, LINE> &keep, const R *lane_best, R *wave_best, Body &&body)
+{
+    static_assert(kCluster == 16, "a quarter of the wave per cluster");
+    if (n == 0u) return;
+    if (keep.stop && __ballot(*keep.stop) != 0ull) return;
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const uint32_t quarter = lane >> 4, member = lane & 15u;
+    const uint32_t n_cl = (n + kCluster - 1) / kCluster, n_grp = (n_cl + kCluster - 1) / kCluster;
+    auto mine = [&](const uint32_t v[4]) { return quarter == 0u ? v[0] : quarter == 1u ? v[1] : quarter == 2u ? v[2] : v[3]; };
+    for (uint32_t g0 = 0; g0 < n_grp; g0 += 64u) {
+        bool hit_g = false;
+        if (g0 + lane < n_grp) hit_g = may_hit<R, LINE>(keep.grp[group0 + g0 + lane], keep.cr, keep.reach());
+        unsigned long long groups = __ballot(hit_g);
+        while (groups != 0ull) {
+            uint32_t gpos[4];
+            const uint32_t n_g = pop_four(groups, gpos);
+            const uint32_t c = (g0 + mine(gpos)) * kCluster + member;
+            bool hit_c = false;
+            if (quarter < n_g && c < n_cl) hit_c = may_hit<R, LINE>(keep.cl[cluster0 + c], keep.cr, keep.reach());
+            unsigned long long clusters = __ballot(hit_c);
+            while (clusters != 0ull) {
+                uint32_t cpos[4], cidx[4];
+                const uint32_t n_c = pop_four(clusters, cpos);
+                for (int j = 0; j < 4; ++j) cidx[j] = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)cpos[j]);  // the cluster lane cpos[j] tested
+                const uint32_t i = mine(cidx) * kCluster + member;
+                bool hit_o = false;
+                if (quarter < n_c && i < n) hit_o = may_hit<R, LINE>(keep.bnd[slot0 + i], keep.cr, keep.reach());
+                if (hit_o) {
+                    const Rec rec = recs[i];
+                    body(rec, slot0 + i);
+                }
+                if (__ballot(hit_o) != 0ull) {
+                    if (keep.stop && __ballot(*keep.stop) != 0ull) return;
+                    if (lane_best) *wave_best = wave_min(*lane_best);
+                }
+            }
+        }
+    }
+}
+
 // Object::intersect for every object of the world (src/shapes/objects.rs:185-198 with
 // src/rays.rs:30-34): the ray goes into object space (direction not renormalised), then the
 // per-shape routine runs.  For each object `per(slot, run)` is called once; `run(emit)`
@@ -753,12 +828,18 @@ RT_DEV void walk_chained(const SceneDev<R> &S, V3<R> ro, V3<R> rd, Per &&per)
     }
 }
 
-// `table(recs, n, slot0, cluster0, group0, body)`: one table, walked wave by wave or lane by lane
-template <typename R, bool CHAIN, bool LANE = false, typename Keep, typename Per>
-RT_DEV void walk_scene(const SceneDev<R> &S, V3<R> ro, V3<R> rd, const Keep &keep, Per &&per)
+// `table(recs, n, slot0, cluster0, group0, body)`: one table, walked wave by wave, lane by lane, or by
+// the whole wave for one ray (lane_best, wave_best: see wide_walk_table)
+template <typename R, bool CHAIN, int WALK = WALK_WAVE, typename Keep, typename Per>
+RT_DEV void walk_scene(const SceneDev<R> &S, V3<R> ro, V3<R> rd, const Keep &keep, Per &&per, const R *lane_best = nullptr,
+                       R *wave_best = nullptr)
 {
-    if constexpr (LANE && Keep::clustered) {
+    if constexpr (WALK != WALK_WAVE && Keep::clustered) {
         uint32_t base = 0;
+        auto lane_walk_table = [&](auto recs, uint32_t n, uint32_t slot0, uint32_t cluster0, uint32_t group0, const Keep &k, auto &&body) {
+            if constexpr (WALK == WALK_WIDE) wide_walk_table(recs, n, slot0, cluster0, group0, k, lane_best, wave_best, body);
+            else rtx::lane_walk_table(recs, n, slot0, cluster0, group0, k, body);
+        };
         lane_walk_table(S.sph, S.n_sph, base, S.cl_off[SH_SPHERE], S.grp_off[SH_SPHERE], keep, [&](const XformRec<R> &rec, uint32_t slot) {
             const V3<R> o = xform_point(rec.m, ro);
             const V3<R> d = xform_vector(rec.m, rd);
@@ -1023,7 +1104,7 @@ struct Hit {
 
 constexpr uint32_t kNone = 0xffffffffu;
 
-template <typename R, bool TRACK, bool COLD_LDS = false, typename Walk>
+template <typename R, bool TRACK, bool COLD_LDS = false, bool WIDE = false, typename Walk>
 RT_DEV Hit<R> closest_hit_with(const SceneDev<R> &S, Walk &&walk)
 {
     Hit<R> h;
@@ -1076,17 +1157,41 @@ RT_DEV Hit<R> closest_hit_with(const SceneDev<R> &S, Walk &&walk)
         if constexpr (COLD_LDS) h.obj = ColdTable<R, true>::slot_obj(S)[h.slot];
         else h.obj = ro_load(S.slot_obj + h.slot);
     }
+    if constexpr (WIDE) {
+        // one ray, every lane with the closest hit among the objects it tested itself: the ray's is the
+        // smallest t, and among equal t the object that comes first in World.objects
+        static_assert(!TRACK, "the container bookkeeping is not joined across lanes");
+        const R t_min = wave_min(h.t);
+        const uint32_t mine = (h.slot != kNone && h.t == t_min) ? h.obj : kNone;
+        const uint32_t first = wave_min(mine);
+        const unsigned long long who = __ballot(mine == first && first != kNone);
+        if (who == 0ull) {
+            h.t = Num<R>::inf;
+            h.slot = h.obj = kNone;
+        } else {
+            const int src = __builtin_ctzll(who);
+            h.t = __shfl(h.t, src);
+            h.slot = __shfl(h.slot, src);
+            h.obj = first;
+        }
+    }
     return h;
 }
 // The closest-hit walks.  t_limit: hits beyond it need not be found (inf for color_at; the
 // distance to the light for a shadow ray, which only asks whether the closest hit lies before it).
-template <typename R, bool TRACK, bool CULL, bool CHAIN, bool LANE = false, bool COLD_LDS = false>
+template <typename R, bool TRACK, bool CULL, bool CHAIN, int WALK = WALK_WAVE, bool COLD_LDS = false>
 RT_DEV Hit<R> closest_hit(const SceneDev<R> &S, V3<R> ro, V3<R> rd, R t_limit)
 {
-    if constexpr (CULL) {
+    if constexpr (CULL && WALK == WALK_WIDE) {
+        return closest_hit_with<R, TRACK, COLD_LDS, true>(S, [&](const R *best, auto &&per) {
+            R wave_best = Num<R>::inf;  // the closest hit any lane has found so far (refreshed after every batch of exact tests)
+            const SphereCull<R, TRACK> keep = { S.bnd, S.cl, S.grp, cull_ray<R, TRACK>(S, ro, rd), &wave_best, t_limit, nullptr };
+            walk_scene<R, CHAIN, WALK_WIDE>(S, ro, rd, keep, per, best, &wave_best);
+        });
+    } else if constexpr (CULL) {
         return closest_hit_with<R, TRACK, COLD_LDS>(S, [&](const R *best, auto &&per) {
             const SphereCull<R, TRACK> keep = { S.bnd, S.cl, S.grp, cull_ray<R, TRACK>(S, ro, rd), best, t_limit, nullptr };
-            walk_scene<R, CHAIN, LANE>(S, ro, rd, keep, per);
+            walk_scene<R, CHAIN, WALK>(S, ro, rd, keep, per);
         });
     } else {
         return closest_hit_with<R, TRACK, COLD_LDS>(S, [&](const R *, auto &&per) { walk_scene<R, CHAIN>(S, ro, rd, KeepAll(), per); });
@@ -1108,7 +1213,7 @@ RT_DEV Hit<R> closest_hit_primary(const SceneDev<R> &S, const PrimScene<R> &P, V
 // src/scenes/world.rs:146-158.  shadowed iff the closest hit (t >= 0) lies before the light
 // and its object casts a shadow.  When every object casts, any hit with 0 <= t < distance
 // decides it, so the walk needs no closest-hit bookkeeping.
-template <typename R, uint32_t SF, bool LANE = false, bool COLD_LDS = false>
+template <typename R, uint32_t SF, int WALK = WALK_WAVE, bool COLD_LDS = false>
 RT_DEV bool is_shadowed(const SceneDev<R> &S, V3<R> p, V3<R> dir, R distance)
 {
     constexpr bool CULL = (SF & SF_CULL) != 0;
@@ -1122,13 +1227,14 @@ RT_DEV bool is_shadowed(const SceneDev<R> &S, V3<R> p, V3<R> dir, R distance)
         };
         if constexpr (CULL) {
             const SphereCull<R, false> keep = { S.bnd, S.cl, S.grp, cull_ray<R, false>(S, p, dir), nullptr, distance, &shadowed };
-            walk_scene<R, CHAIN, LANE>(S, p, dir, keep, per);
+            walk_scene<R, CHAIN, WALK>(S, p, dir, keep, per);
+            if constexpr (WALK == WALK_WIDE) shadowed = __ballot(shadowed) != 0ull;  // any lane's object
         } else {
             walk_scene<R, CHAIN>(S, p, dir, KeepAll(), per);
         }
         return shadowed;
     } else {
-        Hit<R> h = closest_hit<R, false, CULL, CHAIN, LANE, COLD_LDS>(S, p, dir, distance);
+        Hit<R> h = closest_hit<R, false, CULL, CHAIN, WALK, COLD_LDS>(S, p, dir, distance);
         if (h.slot == kNone) return false;
         return h.t < distance && (ColdTable<R, COLD_LDS>::base(S)[h.obj].flags & OF_CASTS_SHADOW) != 0;
     }
@@ -1239,11 +1345,11 @@ struct NoChildrenHook {
     template <typename N> RT_DEV void operator()(const N &) const {}
 };
 // Everything of a color_at node that follows the closest hit `h` of the ray (ro, rd).
-template <typename R, uint32_t SF, bool PRIMARY = false, bool LANE = false, bool COLD_LDS = false, typename Children = NoChildrenHook>
+template <typename R, uint32_t SF, bool PRIMARY = false, int WALK = WALK_WAVE, bool COLD_LDS = false, typename Children = NoChildrenHook>
 RT_DEV Node<R> shade_node(const SceneDev<R> &S, V3<R> ro, V3<R> rd, uint32_t remaining, const Hit<R> &h,
                           Children &&children = Children());
 
-template <typename R, uint32_t SF, bool PRIMARY = false, bool LANE = false, bool COLD_LDS = false, typename Children = NoChildrenHook>
+template <typename R, uint32_t SF, bool PRIMARY = false, int WALK = WALK_WAVE, bool COLD_LDS = false, typename Children = NoChildrenHook>
 RT_DEV Node<R> trace_node(const SceneDev<R> &S, const PrimScene<R> *P, V3<R> ro, V3<R> rd, uint32_t remaining,
                           Children &&children = Children())
 {
@@ -1253,12 +1359,12 @@ RT_DEV Node<R> trace_node(const SceneDev<R> &S, const PrimScene<R> *P, V3<R> ro,
     constexpr bool CHAIN = (SF & SF_CHAIN) != 0;
     RTX_PHASE_BEGIN();
     if constexpr (PRIMARY) h = closest_hit_primary<R, TRACK, CULL, CHAIN>(S, *P, ro, rd);
-    else h = closest_hit<R, TRACK, CULL, CHAIN, LANE, COLD_LDS>(S, ro, rd, Num<R>::inf);
+    else h = closest_hit<R, TRACK, CULL, CHAIN, WALK, COLD_LDS>(S, ro, rd, Num<R>::inf);
     RTX_PHASE_MARK(PRIMARY ? 8 : 0);
-    return shade_node<R, SF, PRIMARY, LANE, COLD_LDS>(S, ro, rd, remaining, h, children);
+    return shade_node<R, SF, PRIMARY, WALK, COLD_LDS>(S, ro, rd, remaining, h, children);
 }
 
-template <typename R, uint32_t SF, bool PRIMARY, bool LANE, bool COLD_LDS, typename Children>
+template <typename R, uint32_t SF, bool PRIMARY, int WALK, bool COLD_LDS, typename Children>
 RT_DEV Node<R> shade_node(const SceneDev<R> &S, V3<R> ro, V3<R> rd, uint32_t remaining, const Hit<R> &h, Children &&children)
 {
     constexpr bool TRACK = (SF & SF_TRANSPARENT) != 0;
@@ -1379,7 +1485,7 @@ RT_DEV Node<R> shade_node(const SceneDev<R> &S, V3<R> ro, V3<R> rd, uint32_t rem
     V3<R> lvec = { S.light_pos[0] - over.x, S.light_pos[1] - over.y, S.light_pos[2] - over.z };
     R ldist;
     V3<R> lightv = normalized(lvec, (lvec.x * lvec.x + lvec.y * lvec.y) + lvec.z * lvec.z, &ldist);
-    bool shadowed = is_shadowed<R, SF, LANE, COLD_LDS>(S, over, lightv, ldist);
+    bool shadowed = is_shadowed<R, SF, WALK, COLD_LDS>(S, over, lightv, ldist);
     nd.shadowed = shadowed;
     RTX_PHASE_MARK(PRIMARY ? 11 : 3);
 

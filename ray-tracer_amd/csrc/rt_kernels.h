@@ -130,7 +130,7 @@ RT_DEV void primary_ray(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> ro, V
     nd.lighting = { R(0), R(0), R(0) };
     const uint32_t sub = blockIdx.x & out_q.sub_mask;
     if (valid) {
-        nd = trace_node<R, SF, CAM, false>(S, CAM ? &P : nullptr, ro, rd, remaining, [&](const Node<R> &c) {
+        nd = trace_node<R, SF, CAM, WALK_WAVE>(S, CAM ? &P : nullptr, ro, rd, remaining, [&](const Node<R> &c) {
             if constexpr ((SF & (SF_REFLECTIVE | SF_TRANSPARENT)) != 0)
                 queue_push2(out_q, sub, c.has_reflect, c.over_point, c.reflectv, c.reflect_factor, c.has_refract, c.under_point,
                             c.refract_dir, c.refract_factor, k);
