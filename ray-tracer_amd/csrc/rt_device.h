@@ -586,9 +586,10 @@ template <typename Rec> RT_DEV Rec load_lds(uint32_t byte_off, uint32_t i)
 // keep.object(slot) says whether this lane's ray can hit the object at all; the record is fetched
 // only when some lane's can.  With Keep::clustered the slots are visited group by group and
 // cluster by cluster, and keep.group(g) / keep.cluster(c) are asked first.
+// group_order: the order in which to meet the table's groups (table-relative indices), or null for table order
 template <typename Rec, typename Keep, typename Body>
 RT_DEV void walk_table(const Rec *recs, uint32_t n, uint32_t slot0, uint32_t cluster0, uint32_t group0, const Keep &keep,
-                       Body &&body, uint32_t lds_off = 0xffffffffu)
+                       Body &&body, uint32_t lds_off = 0xffffffffu, const uint32_t *group_order = nullptr)
 {
     if constexpr (Keep::clustered) {
         // Spheres are fetched four at a time: a walk is a chain of scalar loads, each of which
@@ -596,7 +597,10 @@ RT_DEV void walk_table(const Rec *recs, uint32_t n, uint32_t slot0, uint32_t clu
         // wait then covers four of them.  kCluster is a multiple of 4; the tables are padded.
         static_assert(kCluster % 4 == 0, "spheres are fetched in fours");
         const uint32_t n_cl = (n + kCluster - 1) / kCluster;
-        for (uint32_t g = group0, c0 = 0; c0 < n_cl; ++g, c0 += kCluster) {
+        const uint32_t n_grp = (n_cl + kCluster - 1) / kCluster;
+        for (uint32_t turn = 0; turn < n_grp; ++turn) {
+            const uint32_t g_rel = group_order ? ro_load(group_order + turn) : turn;
+            const uint32_t g = group0 + g_rel, c0 = g_rel * kCluster;
             RTX_WALK_COUNT(0);
             const bool kg = keep.group(g);
             if (__ballot(kg) == 0ull) continue;
@@ -953,11 +957,12 @@ template <typename R, bool CHAIN, typename Keep, typename Per>
 RT_DEV void walk_scene_primary(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> ro, V3<R> rd, const Keep &keep, Per &&per)
 {
     uint32_t slot0 = 0;
+    const uint32_t *const order = Keep::clustered ? P.grp_order : nullptr;
     walk_table(P.sph, P.n_sph, slot0, S.cl_off[SH_SPHERE], S.grp_off[SH_SPHERE], keep, [&](const PrimSphereRec<R> &rec, uint32_t slot) {
         const V3<R> o = { rec.o[0], rec.o[1], rec.o[2] };
         const V3<R> d = primary_direction(S, slot, rec.m, rd);
         per(slot, [&](auto &&emit) { isect_sphere(o, d, rec.c, emit); });
-    });
+    }, 0xffffffffu, order ? order + S.grp_off[SH_SPHERE] : nullptr);
     slot0 += P.n_sph;
     walk_table(P.pln, P.n_pln, slot0, 0u, 0u, KeepAll(), [&](const PrimPlaneRec<R> &rec, uint32_t slot) {
         const R dy = (ro_load(S.slot_flags + slot) & SLOT_DIAGONAL) ? rec.m[1] * rd.y : (rec.m[0] * rd.x + rec.m[1] * rd.y) + rec.m[2] * rd.z;
@@ -969,14 +974,14 @@ RT_DEV void walk_scene_primary(const SceneDev<R> &S, const PrimScene<R> &P, V3<R
         const V3<R> lo = { rec.lo[0], rec.lo[1], rec.lo[2] };
         const V3<R> hi = { rec.hi[0], rec.hi[1], rec.hi[2] };
         per(slot, [&](auto &&emit) { isect_cube(lo, hi, d, emit); });
-    });
+    }, 0xffffffffu, order ? order + S.grp_off[SH_CUBE] : nullptr);
     slot0 += P.n_cub;
     walk_table(P.cyl, P.n_cyl, slot0, S.cl_off[SH_CYLINDER], S.grp_off[SH_CYLINDER], keep, [&](const PrimCappedRec<R> &rec, uint32_t slot) {
         const V3<R> o = { rec.o[0], rec.o[1], rec.o[2] };
         const V3<R> o2 = { rec.o2[0], rec.o2[1], rec.o2[2] };
         const V3<R> d = primary_direction(S, slot, rec.m, rd);
         per(slot, [&](auto &&emit) { isect_cylinder(o, o2, rec.c, d, rec.ymin, rec.ymax, rec.closed != 0, emit); });
-    });
+    }, 0xffffffffu, order ? order + S.grp_off[SH_CYLINDER] : nullptr);
     slot0 += P.n_cyl;
     walk_table(P.con, P.n_con, slot0, 0u, 0u, KeepAll(), [&](const PrimCappedRec<R> &rec, uint32_t slot) {
         const V3<R> o = { rec.o[0], rec.o[1], rec.o[2] };
@@ -1042,6 +1047,35 @@ RT_DEV void make_primary_record(const SceneDev<R> &S, const PrimScene<R> &P, V3<
     out.ymin = src.ymin; out.ymax = src.ymax; out.closed = src.closed;
     for (auto &w : out.pad) w = 0;
     const_cast<PrimCappedRec<R> *>(is_cyl ? P.cyl : P.con)[i] = out;
+}
+
+// Place of group `g` (index into S.grp) among the groups of its shape table when they are ordered by
+// how far along a ray from the camera they can first be met (distance of the centre minus the
+// radius; unbounded groups first, ties by index): one thread per group, a count over its table.
+template <typename R>
+RT_DEV void rank_group(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> cam_origin, uint32_t g)
+{
+    const uint32_t counts[5] = { S.n_sph, S.n_pln, S.n_cub, S.n_cyl, S.n_con };
+    for (uint32_t shape = 0; shape < 5u; ++shape) {
+        if (shape == SH_PLANE || shape == SH_CONE) continue;  // never walked through the hierarchy
+        const uint32_t n_cl = (counts[shape] + kCluster - 1) / kCluster, n_grp = (n_cl + kCluster - 1) / kCluster;
+        const uint32_t first = S.grp_off[shape];
+        if (g < first || g >= first + n_grp) continue;
+        auto key = [&](uint32_t k) {
+            const BoundRec<R> b = S.grp[k];
+            const V3<R> m = { b.c[0] - cam_origin.x, b.c[1] - cam_origin.y, b.c[2] - cam_origin.z };
+            const R d = Num<R>::sqrt_(dot3(m, m)) - b.r;
+            return d == d ? d : -Num<R>::inf;  // an unbounded group (inf - inf) is met first
+        };
+        const R mine = key(g);
+        uint32_t rank = 0;
+        for (uint32_t k = first; k < first + n_grp; ++k) {
+            const R other = key(k);
+            rank += (other < mine || (other == mine && k < g)) ? 1u : 0u;
+        }
+        const_cast<uint32_t *>(P.grp_order)[first + rank] = g - first;
+        return;
+    }
 }
 
 // Where a kernel reads the shading records from.  The rays of a bounce wave hit different

@@ -127,6 +127,11 @@ struct PrimScene {
     const PrimCappedRec<R> *con;
     uint32_t n_sph, n_pln, n_cub, n_cyl, n_con;
     uint32_t pad;
+    // Scenes with bounding-sphere tests: for every shape table, its groups in the order of their distance
+    // from the camera (entry k of a table's run is the table-relative index of the k-th nearest group;
+    // the run of shape s starts at SceneDev::grp_off[s]).  Primary rays meet the groups in that order,
+    // so that what they hit nearby rules out the groups farther away before those are entered.
+    const uint32_t *grp_order;
 };
 
 // Shading record: read once per shaded hit, gathered per lane by original object index.
@@ -165,6 +170,7 @@ struct SceneDev {
     uint32_t n;
     uint32_t flags;
     uint32_t n_chn;
+    uint32_t n_grp_total;      // entries of grp (all shape tables)
     R light_pos[3];
     R light_int[3];
     R world_c[3];   // sphere around every object that has a finite bounding sphere (bounding-sphere
@@ -206,7 +212,10 @@ struct QueueDev {
 
 // Per-level counters, one block of shards per render call (summed on the host).
 // lanes of a lightly loaded chip: 1024 SIMDs x 4 waves x 64 (k_bounce spreads short levels over them)
-constexpr uint32_t kSpreadLanes = 1024u * 4u * 64u;
+#ifndef RTX_SPREAD_LANES
+#define RTX_SPREAD_LANES (1024u * 4u * 64u)
+#endif
+constexpr uint32_t kSpreadLanes = RTX_SPREAD_LANES;
 constexpr int kStatShards = 256;
 struct StatShard {
     unsigned long long hits[8];  // shaded hits (= is_shadowed calls) per recursion level

@@ -668,6 +668,7 @@ int upload_tables(const Tables<R> &t, uint32_t sf, const rtx_scene_desc *d, void
     dev->grp = (const BoundRec<R> *)(base + o_grp);
     dev->chn = (const ChainRec<R> *)(base + o_chn);
     dev->n_chn = (uint32_t)t.chn.size();
+    dev->n_grp_total = (uint32_t)t.grp.size();
     for (int k = 0; k < 5; ++k) {
         dev->cl_off[k] = t.cl_off[k];
         dev->grp_off[k] = t.grp_off[k];
@@ -1012,7 +1013,8 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Workspace &ws, hipEv
         const size_t b_sph = pad(SD.n_sph * sizeof(PrimSphereRec<R>)), b_pln = pad(SD.n_pln * sizeof(PrimPlaneRec<R>)),
                      b_cub = pad(SD.n_cub * sizeof(PrimCubeRec<R>)), b_cyl = pad(SD.n_cyl * sizeof(PrimCappedRec<R>)),
                      b_con = pad(SD.n_con * sizeof(PrimCappedRec<R>));
-        const size_t need = b_sph + b_pln + b_cub + b_cyl + b_con + 256;
+        const size_t b_order = pad((size_t)SD.n_grp_total * sizeof(uint32_t));
+        const size_t need = b_sph + b_pln + b_cub + b_cyl + b_con + b_order + 256;
         if (ws.fixed) {
             if (need > ws.prim_bytes)
                 return fail(RTX_ERR_INVALID, "scene too large for the fixed workspace: its primary-ray tables need %zu bytes, it holds %zu",
@@ -1029,6 +1031,7 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Workspace &ws, hipEv
         prim.cub = (const PrimCubeRec<R> *)(base + b_sph + b_pln);
         prim.cyl = (const PrimCappedRec<R> *)(base + b_sph + b_pln + b_cub);
         prim.con = (const PrimCappedRec<R> *)(base + b_sph + b_pln + b_cub + b_cyl);
+        prim.grp_order = (const uint32_t *)(base + b_sph + b_pln + b_cub + b_cyl + b_con);
         prim.n_sph = SD.n_sph; prim.n_pln = SD.n_pln; prim.n_cub = SD.n_cub; prim.n_cyl = SD.n_cyl; prim.n_con = SD.n_con;
     }
     // The first launch of a frame zeroes the queue and hit counters and fills the primary-ray tables.
