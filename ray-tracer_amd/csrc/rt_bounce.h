@@ -14,11 +14,11 @@ template <> RT_DEV void fb_add<double>(double *p, double v) { unsafeAtomicAdd(p,
 template <> RT_DEV void fb_add<float>(float *p, float v) { unsafeAtomicAdd(p, v); }
 
 // One recursion level.  blockIdx.y selects the input sub-queue; the gridDim.x workgroups of that
-// row read its actual length on the device and share its rays, kRayBlock at a time (workgroup x
+// row read its actual length on the device and share its rays, a piece (bounce_block rays) at a time (workgroup x
 // takes blocks x, x + gridDim.x, ...): the launch has as many waves as the chip holds, whatever
 // the worst-case capacity of the queue is.  The children of block b of sub-queue y go to output
 // sub-queue (b + y) mod n_sub, so every output sub-queue is fed by at most one block per block
-// index: ceil(cap_sub / kRayBlock) * kRayBlock * children-per-ray entries, which is the bound
+// index: ceil(cap_sub / bounce_block) * bounce_block * children-per-ray entries, which is the bound
 // the host sizes the next level's cap_sub with.
 // The object tables are read through constant-address-space pointers (load_uniform), which keeps
 // them in scalar registers although the loop body stores to memory.
@@ -88,10 +88,11 @@ static __device__ double g_slow_rays[64 * 8];
 #define RTX_BOUNCE_ATTR
 #endif
 template <typename R, uint32_t SF, bool COLD_LDS>
-__global__ void __launch_bounds__(kRayBlock<R>) RTX_BOUNCE_ATTR
+__global__ void __launch_bounds__(bounce_block<R>(SF)) RTX_BOUNCE_ATTR
 k_bounce(BounceArgs<R> args_in_kernarg_segment)
 {
-    __shared__ QueueChunk lds[kRayBlock<R> * kEntryChunks<R>];
+    constexpr uint32_t kPiece = bounce_block<R>(SF);  // rays per piece = threads per workgroup
+    __shared__ QueueChunk lds[kPiece * kEntryChunks<R>];
 #ifdef RTX_BOUNCE_LDS_PAD  // occupancy experiments: LDS nobody uses limits the workgroups per CU
     __shared__ uint32_t lds_pad[RTX_BOUNCE_LDS_PAD / 4];
     if (threadIdx.x == 0xffffffu) lds_pad[blockIdx.x] = 1u;
@@ -101,7 +102,7 @@ k_bounce(BounceArgs<R> args_in_kernarg_segment)
         (const RT_CONSTANT_AS BounceArgs<R> *)__builtin_amdgcn_kernarg_segment_ptr();
     const uint32_t sub_in = blockIdx.y;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t step = gridDim.x * kRayBlock<R>;
+    const uint32_t step = gridDim.x * kPiece;
     // one ray per wave for short levels: scenes with the sphere hierarchy whose rays carry no container
     // bookkeeping (that is kept per lane and not joined across lanes)
     constexpr bool kWide = (SF & SF_CULL) != 0 && (SF & SF_TRANSPARENT) == 0 && !kLaneWalk;
@@ -109,7 +110,7 @@ k_bounce(BounceArgs<R> args_in_kernarg_segment)
 #ifdef RTX_LDS_TABLES
     if constexpr ((SF & SF_CULL) == 0) stage_tables<R>(args_in_kernarg_segment.S);
 #endif
-    if constexpr (COLD_LDS) stage_cold_table<R>(args_in_kernarg_segment.S, kRayBlock<R>);
+    if constexpr (COLD_LDS) stage_cold_table<R>(args_in_kernarg_segment.S, kPiece);
     V3<R> ro = { R(0), R(0), R(0) }, rd = ro;
     R weight = R(0);
     uint32_t pixel = 0;
@@ -120,7 +121,7 @@ k_bounce(BounceArgs<R> args_in_kernarg_segment)
     // is the frequency the chip ran at while this launch was resident
     const unsigned long long clk0 = __builtin_readcyclecounter(), real0 = wall_clock64();
 #endif
-    for (uint32_t base = blockIdx.x * kRayBlock<R>;; base += step) {
+    for (uint32_t base = blockIdx.x * kPiece;; base += step) {
         // the compiler must not know that kp is the same pointer as in the last round, or it
         // hoists every load from it out of the loop (some fifty scalar registers)
         asm volatile("" : "+s"(kp));
@@ -138,7 +139,7 @@ k_bounce(BounceArgs<R> args_in_kernarg_segment)
         uint32_t spread = 1u;
         if constexpr ((SF & SF_CULL) != 0 && !kLaneWalk) {
             const uint32_t budget = kSpreadLanes / gridDim.y;  // lanes per sub-queue when the chip is lightly loaded
-            const uint64_t room = ((uint64_t)A.in_q.cap_sub + kRayBlock<R> - 1) / kRayBlock<R> * kRayBlock<R>;
+            const uint64_t room = ((uint64_t)A.in_q.cap_sub + kPiece - 1) / kPiece * kPiece;
             while (spread < 64u && (uint64_t)n * (spread * 2u) <= budget && (uint64_t)n * (spread * 2u) <= room) spread *= 2u;
             // A level of at most kWideRays rays gets a wave per ray, whose 64 lanes walk the sphere hierarchy
             // side by side (wide_walk_table): 64 waves per SIMD at most, each some 30 steps long.
@@ -172,7 +173,7 @@ k_bounce(BounceArgs<R> args_in_kernarg_segment)
         nd.hit = false;
         nd.has_reflect = nd.has_refract = false;
         nd.lighting = { R(0), R(0), R(0) };
-        const uint32_t block = base / kRayBlock<R>;
+        const uint32_t block = base / kPiece;
         const uint32_t sub = (block + sub_in) & A.out_q.sub_mask;
         const R w = weight;
         const uint32_t px_index = pixel;
@@ -276,13 +277,13 @@ RT_DEV void entry_load(const QueueDev<R> &q, uint32_t sub, uint32_t idx, V3<R> &
     pixel = pixel_bits_load<R>(v[7]);
 }
 template <typename R, uint32_t SF>
-__global__ void __launch_bounds__(kRayBlock<R>) k_split_intersect(BounceArgs<R> A, HitRec<R> *__restrict__ hits)
+__global__ void __launch_bounds__(bounce_block<R>(SF)) k_split_intersect(BounceArgs<R> A, HitRec<R> *__restrict__ hits)
 {
     const uint32_t sub = blockIdx.y;
     uint32_t n = ro_load(A.in_q.count + (size_t)sub * kCountStride);
     if (n > A.in_q.cap_sub) n = A.in_q.cap_sub;
-    if (blockIdx.x * kRayBlock<R> >= n) return;
-    const uint32_t k = blockIdx.x * kRayBlock<R> + threadIdx.x;
+    if (blockIdx.x * bounce_block<R>(SF) >= n) return;
+    const uint32_t k = blockIdx.x * bounce_block<R>(SF) + threadIdx.x;
     if (k >= n) return;
     V3<R> ro, rd;
     R weight;
@@ -293,13 +294,13 @@ __global__ void __launch_bounds__(kRayBlock<R>) k_split_intersect(BounceArgs<R> 
     hits[(size_t)sub * A.in_q.cap_sub + k] = out;
 }
 template <typename R, uint32_t SF>
-__global__ void __launch_bounds__(kRayBlock<R>) k_split_shade(BounceArgs<R> A, const HitRec<R> *__restrict__ hits)
+__global__ void __launch_bounds__(bounce_block<R>(SF)) k_split_shade(BounceArgs<R> A, const HitRec<R> *__restrict__ hits)
 {
     const uint32_t sub_in = blockIdx.y;
     uint32_t n = ro_load(A.in_q.count + (size_t)sub_in * kCountStride);
     if (n > A.in_q.cap_sub) n = A.in_q.cap_sub;
-    if (blockIdx.x * kRayBlock<R> >= n) return;
-    const uint32_t k = blockIdx.x * kRayBlock<R> + threadIdx.x;
+    if (blockIdx.x * bounce_block<R>(SF) >= n) return;
+    const uint32_t k = blockIdx.x * bounce_block<R>(SF) + threadIdx.x;
     const bool valid = k < n;
     Node<R> nd;
     nd.hit = false;
@@ -337,7 +338,8 @@ hipError_t launch_bounce(uint32_t sf, hipStream_t stream, const SceneDev<R> &sce
 {
     if ((sf & (SF_REFLECTIVE | SF_TRANSPARENT)) == 0 || in_q.cap_sub == 0) return hipSuccess;  // nothing can be queued
     const uint32_t n_sub = in_q.sub_mask + 1;
-    const uint32_t worst = ((longest ? longest : in_q.cap_sub) + kRayBlock<R> - 1) / kRayBlock<R>;
+    const uint32_t piece = bounce_block<R>(sf);
+    const uint32_t worst = ((longest ? longest : in_q.cap_sub) + piece - 1) / piece;
     const uint32_t share = resident_blocks / n_sub > 0 ? resident_blocks / n_sub : 1u;
     const dim3 grid(worst < share ? worst : share, n_sub);
     const BounceArgs<R> args = { scene, in_q, out_q, remaining, level, fb, stats };
@@ -359,8 +361,8 @@ hipError_t launch_bounce(uint32_t sf, hipStream_t stream, const SceneDev<R> &sce
         HitRec<R> *hits = static_cast<HitRec<R> *>(hit_buffer);
 #define RTX_CALL(SFV)                                                                                   \
     if constexpr (((SFV) & (SF_REFLECTIVE | SF_TRANSPARENT)) != 0) {                                    \
-        hipLaunchKernelGGL((k_split_intersect<R, SFV | SF_PATTERN>), full, dim3(kRayBlock<R>), 0, stream, args, hits); \
-        hipLaunchKernelGGL((k_split_shade<R, SFV | SF_PATTERN>), full, dim3(kRayBlock<R>), 0, stream, args, hits);     \
+        hipLaunchKernelGGL((k_split_intersect<R, SFV | SF_PATTERN>), full, dim3(piece), 0, stream, args, hits); \
+        hipLaunchKernelGGL((k_split_shade<R, SFV | SF_PATTERN>), full, dim3(piece), 0, stream, args, hits);     \
     }
         RTX_SF_SWITCH(sf, RTX_CALL)
 #undef RTX_CALL
@@ -379,11 +381,11 @@ hipError_t launch_bounce(uint32_t sf, hipStream_t stream, const SceneDev<R> &sce
     if constexpr (((SFV) & (SF_REFLECTIVE | SF_TRANSPARENT)) != 0) {                                    \
         if constexpr (((SFV) & SF_CULL) == 0) {                                                         \
             if (cold_bytes)                                                                             \
-                hipLaunchKernelGGL((k_bounce<R, SFV | SF_PATTERN, true>), grid, dim3(kRayBlock<R>), cold_bytes, stream, args); \
+                hipLaunchKernelGGL((k_bounce<R, SFV | SF_PATTERN, true>), grid, dim3(piece), cold_bytes, stream, args); \
             else                                                                                        \
-                hipLaunchKernelGGL((k_bounce<R, SFV | SF_PATTERN, false>), grid, dim3(kRayBlock<R>), table_lds_bytes(scene), stream, args); \
+                hipLaunchKernelGGL((k_bounce<R, SFV | SF_PATTERN, false>), grid, dim3(piece), table_lds_bytes(scene), stream, args); \
         } else {                                                                                        \
-            hipLaunchKernelGGL((k_bounce<R, SFV | SF_PATTERN, false>), grid, dim3(kRayBlock<R>), table_lds_bytes(scene), stream, args); \
+            hipLaunchKernelGGL((k_bounce<R, SFV | SF_PATTERN, false>), grid, dim3(piece), table_lds_bytes(scene), stream, args); \
         }                                                                                               \
     }
     RTX_SF_SWITCH(sf, RTX_CALL)

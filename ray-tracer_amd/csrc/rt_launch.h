@@ -23,6 +23,17 @@ constexpr uint32_t kBlock = 256;
 #define RTX_RAY_BLOCK_F32 256u
 #endif
 template <typename R> constexpr uint32_t kRayBlock = sizeof(R) == 8 ? RTX_RAY_BLOCK_F64 : RTX_RAY_BLOCK_F32;
+// Rays per piece of a bounce launch (and threads per workgroup of the bounce kernel).  Scenes without
+// bounding-sphere tests stage their shading table in LDS per workgroup and do better with 256 threads
+// in f64 as well (4K glass frame 1.84 -> 1.78 ms); with the tests, whose waves differ widely in length,
+// 256 is slower (10k-object frame 5.97 -> 6.4 ms).
+#ifndef RTX_BOUNCE_BLOCK_F64_SMALL_SCENE
+#define RTX_BOUNCE_BLOCK_F64_SMALL_SCENE 256u
+#endif
+template <typename R> constexpr uint32_t bounce_block(uint32_t sf)
+{
+    return sizeof(R) == 8 ? ((sf & 16u /* SF_CULL */) ? RTX_RAY_BLOCK_F64 : RTX_BOUNCE_BLOCK_F64_SMALL_SCENE) : RTX_RAY_BLOCK_F32;
+}
 // The camera kernel runs one wave per workgroup: its waves share nothing, and single waves fill
 // the chip's last round more evenly than groups of four (4K headline frame: 61 -> 58.5 us).
 constexpr uint32_t kCamBlock = 64;

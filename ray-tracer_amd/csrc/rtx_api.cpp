@@ -742,7 +742,7 @@ struct FramePlan {
 // Queue sizes for chunks of `units` rows / rays.  Workgroup b of the primary kernel appends to
 // sub-queue b mod n_sub and each of its rays (one per thread) queues at most g children, which
 // bounds the level-1 sub-queues; a bounce launch feeds every output sub-queue from exactly
-// ceil(cap_sub / kRayBlock) workgroups, which bounds the next level the same way.
+// ceil(cap_sub / bounce_block) pieces, which bounds the next level the same way.
 template <typename R>
 void size_queues(uint32_t sf, uint32_t levels, uint32_t hsize, uint64_t units, FramePlan *p)
 {
@@ -763,7 +763,7 @@ void size_queues(uint32_t sf, uint32_t levels, uint32_t hsize, uint64_t units, F
         p->cap_sub[L] = cap;
         uint64_t &tot = (L & 1) ? p->odd_entries : p->even_entries;
         tot = std::max(tot, cap * n_sub);
-        cap = ((cap + kRayBlock<R> - 1) / kRayBlock<R>) * kRayBlock<R> * g;
+        cap = ((cap + bounce_block<R>(sf) - 1) / bounce_block<R>(sf)) * bounce_block<R>(sf) * g;
     }
     p->bytes = (size_t)((p->odd_entries + p->even_entries) * 8 * sizeof(R));
 }
@@ -812,7 +812,7 @@ int check_overflow(rtx_context *ctx)
 
 // The bounce levels of one chunk of a measured frame: the level-1 queue (ws.queues, plan.cap_sub[1]
 // entries per sub-queue) has been filled by the primary launch already queued on `stream`.  Before
-// each level the lengths of its sub-queues are read back; block b of sub-queue y (kRayBlock rays,
+// each level the lengths of its sub-queues are read back; block b of sub-queue y (bounce_block rays,
 // the last one fewer) sends its children to sub-queue (b + y) mod n_sub of the next queue
 // (k_bounce), which is therefore sized for the largest sum of such blocks times the children a ray
 // can have.  A level without rays ends the chunk.
@@ -829,6 +829,7 @@ int enqueue_measured_levels(rtx_context *ctx, const rtx_scene *scene, Workspace 
         HIP_TRY(hipHostGetDevicePointer((void **)&ws.host_counts_dev, ws.host_counts, 0));
     }
     uint64_t cap_in = plan.cap_sub[1];
+    const uint64_t piece = bounce_block<R>(scene->sf);
     std::vector<uint64_t> feed(n_sub);
     for (uint32_t L = 1; L <= max_depth; ++L) {
         uint32_t *level_counts = counts + (size_t)L * n_sub * kCountStride;
@@ -867,9 +868,9 @@ int enqueue_measured_levels(rtx_context *ctx, const rtx_scene *scene, Workspace 
         for (uint32_t y = 0; y < n_sub; ++y) {
             const uint64_t n = std::min<uint64_t>(ws.host_counts[1 + y], cap_in);
             longest = std::max(longest, n);
-            const uint64_t full = n / kRayBlock<R>, rest = n % kRayBlock<R>;
-            everywhere += (full / n_sub) * kRayBlock<R>;
-            add_run(y, full % n_sub, kRayBlock<R>);
+            const uint64_t full = n / piece, rest = n % piece;
+            everywhere += (full / n_sub) * piece;
+            add_run(y, full % n_sub, piece);
             if (rest) add_run((uint32_t)((full + y) & (n_sub - 1)), 1, rest);
         }
         uint64_t running = 0;
