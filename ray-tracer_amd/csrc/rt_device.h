@@ -500,22 +500,27 @@ template <typename R, bool LINE> RT_DEV CullRay<R> cull_ray(const SceneDev<R> &S
 }
 // LINE: intersections anywhere on the line count (the container bookkeeping of refraction reads
 // those behind the origin too).  Otherwise only 0 <= t <= t_max counts; reach = t_max * |d|.
+// Three quantities, any of which being positive rules the sphere out, joined by a maximum and
+// compared once (no branches, one mask: the walks spend as many scalar instructions as vector
+// ones).  A NaN on one side of a maximum or minimum gives the other side and NaN > 0 is false; the
+// only case in which that differs from three separate comparisons is an origin at infinity,
+// whose exact intersections are all NaN as well.
 template <typename R, bool LINE>
 RT_DEV bool may_hit(const BoundRec<R> &b, const CullRay<R> &cr, R reach)
 {
-    if (cr.dead) return false;
     const V3<R> m = { b.c[0] - cr.o.x, b.c[1] - cr.o.y, b.c[2] - cr.o.z };
     const R tc = cull_fma(m.z, cr.u.z, cull_fma(m.y, cr.u.y, m.x * cr.u.x));
     const R m2 = cull_fma(m.z, m.z, cull_fma(m.y, m.y, m.x * m.x));
     const R r2 = b.r * b.r;
     // squared distance of the centre from the line against r^2; r = inf never skips
-    if (cull_fma(-Num<R>::cull_slack, m2, cull_fma(-tc, tc, m2)) > r2) return false;
+    R out = cull_fma(-Num<R>::cull_slack, m2, cull_fma(-tc, tc, m2)) - r2;
     if constexpr (!LINE) {
-        if (tc < R(0) && m2 > r2) return false;  // the whole sphere lies behind the origin
+        const R behind = Num<R>::min_(-tc, m2 - r2);  // both positive: the whole sphere lies behind the origin
         // the ray is inside the sphere no earlier than tc - r along u
-        if (cull_fma(-Num<R>::cull_slack, Num<R>::abs_(tc), tc - b.r) > reach) return false;
+        const R far = cull_fma(-Num<R>::cull_slack, Num<R>::abs_(tc), tc - b.r) - reach;
+        out = Num<R>::max_(Num<R>::max_(out, behind), far);
     }
-    return true;
+    return !cr.dead & !(out > R(0));
 }
 
 // ---- walking the object tables ---------------------------------------------------------
@@ -665,11 +670,80 @@ struct SphereCull {
         const Four f = load_uniform(reinterpret_cast<const Four *>(first));
         const bool live = outer && !(stop && *stop);
         const R rch = reach();
-        for (int j = 0; j < 4; ++j) out[j] = live && may_hit<R, LINE>(f.b[j], cr, rch);
+        for (int j = 0; j < 4; ++j) out[j] = live & may_hit<R, LINE>(f.b[j], cr, rch);
     }
     RT_DEV void object4(uint32_t slot, bool outer, bool *out) const { four(bnd + slot, outer, out); }
     RT_DEV void cluster4(uint32_t c, bool outer, bool *out) const { four(cl + c, outer, out); }
     RT_DEV bool group(uint32_t g) const { return !(stop && *stop) && may_hit<R, LINE>(load_uniform(grp + g), cr, reach()); }
+};
+
+// The same tests for rays that all start at the camera.  Of the 19 operations of may_hit, 10 work
+// out things that depend on the sphere and the origin alone (centre - origin, its square, r^2);
+// make_primary_bound does those once per frame and sphere, and a primary ray is left with the dot
+// product tc = m.u and three quantities of which any being positive rules the sphere out:
+//   k - tc^2            the line misses it; k = (1 - allowance) m2 - r^2, which is the test of
+//                       may_hit up to two more roundings of size ulp(m2), inside the allowance
+//   behind - tc         the camera is outside it and it lies behind
+//   tc - r - allowance |tc| - reach   it begins beyond the closest hit so far
+// They are joined by a maximum and compared once: a camera wave spends as many scalar
+// instructions as vector ones, and a test written as three short-circuit comparisons costs a
+// dozen of them in mask bookkeeping and branches.  A NaN on one side of a maximum gives the other
+// side and NaN > 0 is false, as with the separate comparisons; r = inf makes all three -inf.
+// The origin is not moved towards the scene here (CullRay::shift is ignored): all of it is
+// relative to the camera itself.
+template <typename R>
+RT_DEV void make_primary_bound(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> cam_origin, uint32_t i)
+{
+    const BoundRec<R> *src;
+    PrimBoundRec<R> *dst;
+    if (i < S.n_bnd_total) { src = S.bnd + i; dst = const_cast<PrimBoundRec<R> *>(P.bnd) + i; }
+    else if ((i -= S.n_bnd_total) < S.n_cl_total) { src = S.cl + i; dst = const_cast<PrimBoundRec<R> *>(P.cl) + i; }
+    else if ((i -= S.n_cl_total) < S.n_grp_total) { src = S.grp + i; dst = const_cast<PrimBoundRec<R> *>(P.grp) + i; }
+    else return;
+    const BoundRec<R> b = *src;
+    PrimBoundRec<R> out;
+    out.m[0] = b.c[0] - cam_origin.x;
+    out.m[1] = b.c[1] - cam_origin.y;
+    out.m[2] = b.c[2] - cam_origin.z;
+    const R m2 = cull_fma(out.m[2], out.m[2], cull_fma(out.m[1], out.m[1], out.m[0] * out.m[0]));
+    const R r2 = b.r * b.r;
+    out.k = cull_fma(-Num<R>::cull_slack, m2, m2) - r2;
+    out.r = b.r;
+    out.behind = m2 > r2 ? R(0) : -Num<R>::inf;
+    *dst = out;
+}
+template <typename R, bool LINE>
+RT_DEV bool may_hit_primary(const PrimBoundRec<R> &b, V3<R> u, R reach)
+{
+    const R tc = cull_fma(b.m[2], u.z, cull_fma(b.m[1], u.y, b.m[0] * u.x));
+    R out = cull_fma(-tc, tc, b.k);
+    if constexpr (!LINE) {
+        const R far = cull_fma(-Num<R>::cull_slack, Num<R>::abs_(tc), tc - b.r) - reach;
+        out = Num<R>::max_(Num<R>::max_(out, b.behind - tc), far);
+    }
+    return !(out > R(0));
+}
+template <typename R, bool LINE>
+struct PrimSphereCull {
+    static constexpr bool clustered = true;
+    const PrimBoundRec<R> *bnd, *cl, *grp;
+    V3<R> u;
+    R dlen;
+    bool dead;  // asked once per group: clusters and objects are reached through a group that passed
+    const R *best;
+    RT_DEV R reach() const { return *best * dlen; }
+    struct Four {
+        PrimBoundRec<R> b[4];
+    };
+    RT_DEV void four(const PrimBoundRec<R> *first, bool outer, bool *out) const
+    {
+        const Four f = load_uniform(reinterpret_cast<const Four *>(first));
+        const R rch = reach();
+        for (int j = 0; j < 4; ++j) out[j] = outer & may_hit_primary<R, LINE>(f.b[j], u, rch);
+    }
+    RT_DEV void object4(uint32_t slot, bool outer, bool *out) const { four(bnd + slot, outer, out); }
+    RT_DEV void cluster4(uint32_t c, bool outer, bool *out) const { four(cl + c, outer, out); }
+    RT_DEV bool group(uint32_t g) const { return !dead & may_hit_primary<R, LINE>(load_uniform(grp + g), u, reach()); }
 };
 
 // Experiment (tools build, -DRTX_LANE_WALK; measured slower, see tools/README.md):
@@ -1236,7 +1310,8 @@ RT_DEV Hit<R> closest_hit_primary(const SceneDev<R> &S, const PrimScene<R> &P, V
 {
     if constexpr (CULL) {
         return closest_hit_with<R, TRACK>(S, [&](const R *best, auto &&per) {
-            const SphereCull<R, TRACK> keep = { S.bnd, S.cl, S.grp, cull_ray<R, TRACK>(S, ro, rd), best, Num<R>::inf, nullptr };
+            const CullRay<R> cr = cull_ray<R, TRACK>(S, ro, rd);
+            const PrimSphereCull<R, TRACK> keep = { P.bnd, P.cl, P.grp, cr.u, cr.dlen, cr.dead, best };
             walk_scene_primary<R, CHAIN>(S, P, ro, rd, keep, per);
         });
     } else {

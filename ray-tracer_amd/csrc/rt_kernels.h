@@ -223,6 +223,7 @@ k_frame_begin(CameraDev<R> cam, SceneDev<R> S, PrimScene<R> P, uint32_t n_tables
     if (i < n_b) zero_b[i] = 0u;
     if (i < n_tables) make_primary_record<R>(S, P, { cam.origin[0], cam.origin[1], cam.origin[2] }, i);
     if (n_tables != 0u && i < S.n_grp_total) rank_group<R>(S, P, { cam.origin[0], cam.origin[1], cam.origin[2] }, i);
+    if (n_tables != 0u && P.bnd) make_primary_bound<R>(S, P, { cam.origin[0], cam.origin[1], cam.origin[2] }, i);
 }
 
 template <typename R>
@@ -368,7 +369,9 @@ hipError_t Launch<R>::frame_begin(hipStream_t stream, const CameraDev<R> *cam, c
                                   const PrimScene<R> &prim, uint32_t *zero_a, uint32_t n_a, uint32_t *zero_b, uint32_t n_b)
 {
     const uint32_t n_tables = cam ? scene.n : 0u;  // (a scene has fewer groups than objects)
-    const uint32_t n = n_tables > n_a ? (n_tables > n_b ? n_tables : n_b) : (n_a > n_b ? n_a : n_b);
+    const uint32_t n_bounds = (cam && prim.bnd) ? scene.n_bnd_total + scene.n_cl_total + scene.n_grp_total : 0u;
+    uint32_t n = n_tables > n_a ? (n_tables > n_b ? n_tables : n_b) : (n_a > n_b ? n_a : n_b);
+    n = n > n_bounds ? n : n_bounds;
     if (n == 0) return hipSuccess;
     CameraDev<R> c = {};
     if (cam) c = *cam;

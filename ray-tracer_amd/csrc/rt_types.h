@@ -118,6 +118,16 @@ struct alignas(sizeof(R) * 2) PrimCappedRec {
     uint32_t closed;
     uint32_t pad[(2 * sizeof(R) - 4) / 4];
 };
+// Bounding sphere of an object, cluster or group as the camera sees it: the tests of a primary ray
+// against it need the centre relative to the camera and three numbers made from the distance and the
+// radius, all the same for every pixel (make_primary_bound fills them, may_hit_primary reads them).
+template <typename R>
+struct alignas(sizeof(R) * 2) PrimBoundRec {
+    R m[3];    // centre - camera origin
+    R k;       // (1 - allowance) * |m|^2 - r^2: the line misses the sphere when k - (m.u)^2 > 0
+    R r;       // radius (+inf: unbounded)
+    R behind;  // the sphere lies behind the camera when m.u < behind: 0 with the camera outside it, else -inf
+};
 template <typename R>
 struct PrimScene {
     const PrimSphereRec<R> *sph;
@@ -132,6 +142,7 @@ struct PrimScene {
     // the run of shape s starts at SceneDev::grp_off[s]).  Primary rays meet the groups in that order,
     // so that what they hit nearby rules out the groups farther away before those are entered.
     const uint32_t *grp_order;
+    const PrimBoundRec<R> *bnd, *cl, *grp;  // same indices as SceneDev::bnd, cl, grp
 };
 
 // Shading record: read once per shaded hit, gathered per lane by original object index.
@@ -171,6 +182,7 @@ struct SceneDev {
     uint32_t flags;
     uint32_t n_chn;
     uint32_t n_grp_total;      // entries of grp (all shape tables)
+    uint32_t n_bnd_total, n_cl_total;  // entries of bnd and of cl, padding included
     R light_pos[3];
     R light_int[3];
     R world_c[3];   // sphere around every object that has a finite bounding sphere (bounding-sphere

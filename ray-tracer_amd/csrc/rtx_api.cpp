@@ -669,6 +669,8 @@ int upload_tables(const Tables<R> &t, uint32_t sf, const rtx_scene_desc *d, void
     dev->chn = (const ChainRec<R> *)(base + o_chn);
     dev->n_chn = (uint32_t)t.chn.size();
     dev->n_grp_total = (uint32_t)t.grp.size();
+    dev->n_bnd_total = (uint32_t)t.bnd.size();
+    dev->n_cl_total = (uint32_t)t.cl.size();
     for (int k = 0; k < 5; ++k) {
         dev->cl_off[k] = t.cl_off[k];
         dev->grp_off[k] = t.grp_off[k];
@@ -1015,7 +1017,12 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Workspace &ws, hipEv
                      b_cub = pad(SD.n_cub * sizeof(PrimCubeRec<R>)), b_cyl = pad(SD.n_cyl * sizeof(PrimCappedRec<R>)),
                      b_con = pad(SD.n_con * sizeof(PrimCappedRec<R>));
         const size_t b_order = pad((size_t)SD.n_grp_total * sizeof(uint32_t));
-        const size_t need = b_sph + b_pln + b_cub + b_cyl + b_con + b_order + 256;
+        // the spheres of the hierarchy relative to the camera (scenes with bounding-sphere tests only)
+        const bool culled = (scene->sf & SF_CULL) != 0;
+        const size_t b_pbnd = culled ? pad((size_t)SD.n_bnd_total * sizeof(PrimBoundRec<R>)) : 0,
+                     b_pcl = culled ? pad((size_t)SD.n_cl_total * sizeof(PrimBoundRec<R>)) : 0,
+                     b_pgrp = culled ? pad((size_t)SD.n_grp_total * sizeof(PrimBoundRec<R>)) : 0;
+        const size_t need = b_sph + b_pln + b_cub + b_cyl + b_con + b_order + b_pbnd + b_pcl + b_pgrp + 256;
         if (ws.fixed) {
             if (need > ws.prim_bytes)
                 return fail(RTX_ERR_INVALID, "scene too large for the fixed workspace: its primary-ray tables need %zu bytes, it holds %zu",
@@ -1032,7 +1039,13 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Workspace &ws, hipEv
         prim.cub = (const PrimCubeRec<R> *)(base + b_sph + b_pln);
         prim.cyl = (const PrimCappedRec<R> *)(base + b_sph + b_pln + b_cub);
         prim.con = (const PrimCappedRec<R> *)(base + b_sph + b_pln + b_cub + b_cyl);
-        prim.grp_order = (const uint32_t *)(base + b_sph + b_pln + b_cub + b_cyl + b_con);
+        char *after = base + b_sph + b_pln + b_cub + b_cyl + b_con;
+        prim.grp_order = (const uint32_t *)after;
+        if (culled) {
+            prim.bnd = (const PrimBoundRec<R> *)(after + b_order);
+            prim.cl = (const PrimBoundRec<R> *)(after + b_order + b_pbnd);
+            prim.grp = (const PrimBoundRec<R> *)(after + b_order + b_pbnd + b_pcl);
+        }
         prim.n_sph = SD.n_sph; prim.n_pln = SD.n_pln; prim.n_cub = SD.n_cub; prim.n_cyl = SD.n_cyl; prim.n_con = SD.n_con;
     }
     // The first launch of a frame zeroes the queue and hit counters and fills the primary-ray tables.
