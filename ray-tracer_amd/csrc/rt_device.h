@@ -710,10 +710,17 @@ RT_DEV void make_primary_bound(const SceneDev<R> &S, const PrimScene<R> &P, V3<R
     out.k = cull_fma(-Num<R>::cull_slack, m2, m2) - r2;
     out.r = b.r;
     out.behind = m2 > r2 ? R(0) : -Num<R>::inf;
+    out.km = cull_fma(R(-4) * Num<R>::cull_slack, m2, m2);
+    out.dist = Num<R>::sqrt_(out.km) * (R(1) - Num<R>::cull_slack);
     *dst = out;
 }
+// what one ray's test reads of a PrimBoundRec
+template <typename R>
+struct alignas(sizeof(R) * 2) PrimBoundHead {
+    R m[3], k, r, behind;
+};
 template <typename R, bool LINE>
-RT_DEV bool may_hit_primary(const PrimBoundRec<R> &b, V3<R> u, R reach)
+RT_DEV bool may_hit_primary(const PrimBoundHead<R> &b, V3<R> u, R reach)
 {
     const R tc = cull_fma(b.m[2], u.z, cull_fma(b.m[1], u.y, b.m[0] * u.x));
     R out = cull_fma(-tc, tc, b.k);
@@ -732,18 +739,17 @@ struct PrimSphereCull {
     bool dead;  // asked once per group: clusters and objects are reached through a group that passed
     const R *best;
     RT_DEV R reach() const { return *best * dlen; }
-    struct Four {
-        PrimBoundRec<R> b[4];
-    };
+    static RT_DEV PrimBoundHead<R> head(const PrimBoundRec<R> *rec) { return load_uniform(reinterpret_cast<const PrimBoundHead<R> *>(rec)); }
     RT_DEV void four(const PrimBoundRec<R> *first, bool outer, bool *out) const
     {
-        const Four f = load_uniform(reinterpret_cast<const Four *>(first));
+        PrimBoundHead<R> b[4];
+        for (int j = 0; j < 4; ++j) b[j] = head(first + j);
         const R rch = reach();
-        for (int j = 0; j < 4; ++j) out[j] = outer & may_hit_primary<R, LINE>(f.b[j], u, rch);
+        for (int j = 0; j < 4; ++j) out[j] = outer & may_hit_primary<R, LINE>(b[j], u, rch);
     }
     RT_DEV void object4(uint32_t slot, bool outer, bool *out) const { four(bnd + slot, outer, out); }
     RT_DEV void cluster4(uint32_t c, bool outer, bool *out) const { four(cl + c, outer, out); }
-    RT_DEV bool group(uint32_t g) const { return !dead & may_hit_primary<R, LINE>(load_uniform(grp + g), u, reach()); }
+    RT_DEV bool group(uint32_t g) const { return !dead & may_hit_primary<R, LINE>(head(grp + g), u, reach()); }
 };
 
 // Experiment (tools build, -DRTX_LANE_WALK; measured slower, see tools/README.md):
@@ -865,6 +871,120 @@ RT_DEV void wide_walk_table(const Rec *recs, uint32_t n, uint32_t slot0, uint32_
                     if (keep.stop && __ballot(*keep.stop) != 0ull) return;
                     if (lane_best) *wave_best = wave_min(*lane_best);
                 }
+            }
+        }
+    }
+}
+
+// The walk for the 64 camera rays of a wave together.  They leave one point and fill a narrow
+// pyramid (an 8x8 tile of pixels), and the wave-uniform walk has every lane test every sphere
+// that any of them may hit: 64 times the same answer, some 700 times per wave in a scene of
+// 10 000 objects.  Here the pyramid is enclosed in a cone (axis a: the mean direction; half-angle:
+// the largest angle of a ray to it, with a margin), and the 64 lanes test 64 spheres of a level
+// against the CONE at once, as wide_walk_table does against one ray: every group of a table in
+// the order nearest first, the 16 clusters of up to four groups the cone touches, the 16 members
+// of up to four such clusters.  What is left are the objects near the tile; those are met one
+// after the other, each lane with the test of its own ray (may_hit_primary) and the exact
+// intersection.  A sphere is ruled out for the whole wave when
+//   its centre is farther than r from the cone: with tc = m.a and perp the distance of the centre
+//     from the axis, perp cos w - tc sin w is its distance from the line the cone's surface makes
+//     in the plane of axis and centre, and the cone lies on the other side of that line;
+//   or every ray of the cone points away from it (tc cos w + |m| sin w < 0, camera outside);
+//   or it begins farther away (|m| - r) than the largest reach of the wave's rays.
+// All three are conservative against the rays' own tests, with allowances for the arithmetic,
+// so the objects that reach an exact intersection include all that can be hit: same pixels.
+template <typename T, typename Op> RT_DEV T wave_reduce(T v, Op &&op)
+{
+    for (int off = 32; off > 0; off >>= 1) v = op(v, __shfl_xor(v, off));
+    return v;
+}
+template <typename R>
+struct Beam {
+    V3<R> a;         // unit axis
+    R sin_w, cos_w;  // of the half-angle (NaN: the rays do not fit a cone of less than a right angle, nothing is ruled out by it)
+};
+// `live`: this lane holds a ray that can hit bounded objects; at least one lane of the wave does
+template <typename R> RT_DEV Beam<R> make_beam(V3<R> u, bool live)
+{
+    auto add = [](R x, R y) { return x + y; };
+    auto larger = [](R x, R y) { return Num<R>::max_(x, y); };
+    const V3<R> mine = live ? u : V3<R>{ R(0), R(0), R(0) };
+    const V3<R> sum = { wave_reduce(mine.x, add), wave_reduce(mine.y, add), wave_reduce(mine.z, add) };
+    const R inv = R(1) / Num<R>::sqrt_(dot3(sum, sum));
+    Beam<R> b;
+    b.a = { sum.x * inv, sum.y * inv, sum.z * inv };
+    const R along = dot3(u, b.a);
+    const V3<R> w = { cull_fma(-along, b.a.x, u.x), cull_fma(-along, b.a.y, u.y), cull_fma(-along, b.a.z, u.z) };
+    const R sin2 = wave_reduce(live ? dot3(w, w) : R(0), larger);
+    const bool wide = __ballot(live && !(along > R(0.1))) != 0ull;
+    b.sin_w = Num<R>::sqrt_(sin2) * R(1.001) + R(64) * Num<R>::cull_slack;
+    if (wide || !(b.sin_w < R(0.99))) b.sin_w = Num<R>::inf - Num<R>::inf;
+    b.cos_w = Num<R>::sqrt_(Num<R>::max_(cull_fma(-b.sin_w, b.sin_w, R(1)), R(0)));
+    return b;
+}
+template <typename R>
+RT_DEV bool beam_may_hit(const PrimBoundRec<R> &b, const Beam<R> &bm, R reach_max)
+{
+    const R tc = cull_fma(b.m[2], bm.a.z, cull_fma(b.m[1], bm.a.y, b.m[0] * bm.a.x));
+    const R perp = Num<R>::sqrt_(Num<R>::max_(cull_fma(-tc, tc, b.km), R(0)));  // a lower bound
+    const R upper = b.dist * (R(1) + R(8) * Num<R>::cull_slack);               // of |m|
+    const R e = R(8) * Num<R>::cull_slack * (Num<R>::abs_(tc) + upper);          // rounding of the sums below
+    const R miss = (cull_fma(perp, bm.cos_w, -(tc * bm.sin_w)) - e) - b.r;
+    const R behind = b.behind - (cull_fma(upper, bm.sin_w, tc * bm.cos_w) + e);
+    const R far = (b.dist - b.r) - reach_max;
+    return !(Num<R>::max_(Num<R>::max_(miss, behind), far) > R(0));
+}
+// group_order: the table's groups nearest first (table-relative indices); u, dlen, best: this lane's ray
+// (unit direction, |direction|, closest hit so far), live as for make_beam.  All 64 lanes call this.
+template <typename R, typename Rec, typename Body>
+RT_DEV void beam_walk_table(const Rec *recs, uint32_t n, uint32_t slot0, uint32_t cluster0, uint32_t group0, const uint32_t *group_order,
+                            const PrimScene<R> &P, const Beam<R> &beam, V3<R> u, R dlen, bool live, const R *best, Body &&body)
+{
+    static_assert(kCluster == 16, "a quarter of the wave per cluster");
+    if (n == 0u) return;
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const uint32_t quarter = lane >> 4, member = lane & 15u;
+    const uint32_t n_cl = (n + kCluster - 1) / kCluster, n_grp = (n_cl + kCluster - 1) / kCluster;
+    auto mine = [&](const uint32_t v[4]) { return quarter == 0u ? v[0] : quarter == 1u ? v[1] : quarter == 2u ? v[2] : v[3]; };
+    auto larger = [](R x, R y) { return Num<R>::max_(x, y); };
+    auto wave_reach = [&]() { return wave_reduce(live ? *best * dlen : -Num<R>::inf, larger); };
+    R reach_max = wave_reach();
+    for (uint32_t g0 = 0; g0 < n_grp; g0 += 64u) {
+        bool hit_g = false;
+        uint32_t g_rel = 0u;
+        if (g0 + lane < n_grp) {
+            g_rel = group_order[g0 + lane];
+            hit_g = beam_may_hit(P.grp[group0 + g_rel], beam, reach_max);
+        }
+        unsigned long long groups = __ballot(hit_g);
+        while (groups != 0ull) {
+            uint32_t gpos[4], gidx[4];
+            const uint32_t n_g = pop_four(groups, gpos);
+            for (int j = 0; j < 4; ++j) gidx[j] = (uint32_t)__builtin_amdgcn_readlane((int)g_rel, (int)gpos[j]);
+            const uint32_t c = mine(gidx) * kCluster + member;
+            bool hit_c = false;
+            if (quarter < n_g && c < n_cl) hit_c = beam_may_hit(P.cl[cluster0 + c], beam, reach_max);
+            unsigned long long clusters = __ballot(hit_c);
+            while (clusters != 0ull) {
+                uint32_t cpos[4], cidx[4];
+                const uint32_t n_c = pop_four(clusters, cpos);
+                for (int j = 0; j < 4; ++j) cidx[j] = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)cpos[j]);
+                const uint32_t i = mine(cidx) * kCluster + member;
+                bool hit_o = false;
+                if (quarter < n_c && i < n) hit_o = beam_may_hit(P.bnd[slot0 + i], beam, reach_max);
+                unsigned long long objects = __ballot(hit_o);
+                if (objects == 0ull) continue;
+                while (objects != 0ull) {
+                    const uint32_t at = (uint32_t)__builtin_ctzll(objects);
+                    objects &= objects - 1ull;
+                    const uint32_t io = (uint32_t)__builtin_amdgcn_readlane((int)i, (int)at);
+                    const PrimBoundHead<R> b = PrimSphereCull<R, false>::head(P.bnd + slot0 + io);
+                    const bool mine_too = live & may_hit_primary<R, false>(b, u, *best * dlen);
+                    if (__ballot(mine_too) == 0ull) continue;
+                    const Rec rec = load_uniform(recs + io);
+                    if (mine_too) body(rec, slot0 + io);
+                }
+                reach_max = wave_reach();
             }
         }
     }
@@ -1027,43 +1147,64 @@ template <typename R> RT_DEV V3<R> primary_direction(const SceneDev<R> &S, uint3
     if (ro_load(S.slot_flags + slot) & SLOT_DIAGONAL) return { m[0] * v.x, m[4] * v.y, m[8] * v.z };
     return xform_vector9(m, v);
 }
-template <typename R, bool CHAIN, typename Keep, typename Per>
-RT_DEV void walk_scene_primary(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> ro, V3<R> rd, const Keep &keep, Per &&per)
+// `bounded(recs, n, slot0, shape, body)` walks one of the three tables whose objects have finite
+// bounding spheres; `unbounded(run)` runs the walks of the others (for the lanes that hold a ray).
+template <typename R, bool CHAIN, typename Bounded, typename Unbounded, typename Per>
+RT_DEV void walk_primary_tables(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> ro, V3<R> rd, Bounded &&bounded,
+                                Unbounded &&unbounded, Per &&per)
 {
-    uint32_t slot0 = 0;
-    const uint32_t *const order = Keep::clustered ? P.grp_order : nullptr;
-    walk_table(P.sph, P.n_sph, slot0, S.cl_off[SH_SPHERE], S.grp_off[SH_SPHERE], keep, [&](const PrimSphereRec<R> &rec, uint32_t slot) {
+    // planes and cones first: what a ray hits there shortens its reach for the tables with a hierarchy
+    unbounded([&]() {
+        walk_table(P.pln, P.n_pln, P.n_sph, 0u, 0u, KeepAll(), [&](const PrimPlaneRec<R> &rec, uint32_t slot) {
+            const R dy = (ro_load(S.slot_flags + slot) & SLOT_DIAGONAL) ? rec.m[1] * rd.y : (rec.m[0] * rd.x + rec.m[1] * rd.y) + rec.m[2] * rd.z;
+            per(slot, [&](auto &&emit) { isect_plane(rec.neg_oy, dy, emit); });
+        });
+        walk_table(P.con, P.n_con, P.n_sph + P.n_pln + P.n_cub + P.n_cyl, 0u, 0u, KeepAll(), [&](const PrimCappedRec<R> &rec, uint32_t slot) {
+            const V3<R> o = { rec.o[0], rec.o[1], rec.o[2] };
+            const V3<R> o2 = { rec.o2[0], rec.o2[1], rec.o2[2] };
+            const V3<R> d = primary_direction(S, slot, rec.m, rd);
+            per(slot, [&](auto &&emit) { isect_cone(o, o2, rec.c, d, rec.ymin, rec.ymax, rec.closed != 0, emit); });
+        });
+        if constexpr (CHAIN) walk_chained(S, ro, rd, per);
+    });
+    bounded(P.sph, P.n_sph, 0u, (uint32_t)SH_SPHERE, [&](const PrimSphereRec<R> &rec, uint32_t slot) {
         const V3<R> o = { rec.o[0], rec.o[1], rec.o[2] };
         const V3<R> d = primary_direction(S, slot, rec.m, rd);
         per(slot, [&](auto &&emit) { isect_sphere(o, d, rec.c, emit); });
-    }, 0xffffffffu, order ? order + S.grp_off[SH_SPHERE] : nullptr);
-    slot0 += P.n_sph;
-    walk_table(P.pln, P.n_pln, slot0, 0u, 0u, KeepAll(), [&](const PrimPlaneRec<R> &rec, uint32_t slot) {
-        const R dy = (ro_load(S.slot_flags + slot) & SLOT_DIAGONAL) ? rec.m[1] * rd.y : (rec.m[0] * rd.x + rec.m[1] * rd.y) + rec.m[2] * rd.z;
-        per(slot, [&](auto &&emit) { isect_plane(rec.neg_oy, dy, emit); });
     });
-    slot0 += P.n_pln;
-    walk_table(P.cub, P.n_cub, slot0, S.cl_off[SH_CUBE], S.grp_off[SH_CUBE], keep, [&](const PrimCubeRec<R> &rec, uint32_t slot) {
+    bounded(P.cub, P.n_cub, P.n_sph + P.n_pln, (uint32_t)SH_CUBE, [&](const PrimCubeRec<R> &rec, uint32_t slot) {
         const V3<R> d = primary_direction(S, slot, rec.m, rd);
         const V3<R> lo = { rec.lo[0], rec.lo[1], rec.lo[2] };
         const V3<R> hi = { rec.hi[0], rec.hi[1], rec.hi[2] };
         per(slot, [&](auto &&emit) { isect_cube(lo, hi, d, emit); });
-    }, 0xffffffffu, order ? order + S.grp_off[SH_CUBE] : nullptr);
-    slot0 += P.n_cub;
-    walk_table(P.cyl, P.n_cyl, slot0, S.cl_off[SH_CYLINDER], S.grp_off[SH_CYLINDER], keep, [&](const PrimCappedRec<R> &rec, uint32_t slot) {
+    });
+    bounded(P.cyl, P.n_cyl, P.n_sph + P.n_pln + P.n_cub, (uint32_t)SH_CYLINDER, [&](const PrimCappedRec<R> &rec, uint32_t slot) {
         const V3<R> o = { rec.o[0], rec.o[1], rec.o[2] };
         const V3<R> o2 = { rec.o2[0], rec.o2[1], rec.o2[2] };
         const V3<R> d = primary_direction(S, slot, rec.m, rd);
         per(slot, [&](auto &&emit) { isect_cylinder(o, o2, rec.c, d, rec.ymin, rec.ymax, rec.closed != 0, emit); });
-    }, 0xffffffffu, order ? order + S.grp_off[SH_CYLINDER] : nullptr);
-    slot0 += P.n_cyl;
-    walk_table(P.con, P.n_con, slot0, 0u, 0u, KeepAll(), [&](const PrimCappedRec<R> &rec, uint32_t slot) {
-        const V3<R> o = { rec.o[0], rec.o[1], rec.o[2] };
-        const V3<R> o2 = { rec.o2[0], rec.o2[1], rec.o2[2] };
-        const V3<R> d = primary_direction(S, slot, rec.m, rd);
-        per(slot, [&](auto &&emit) { isect_cone(o, o2, rec.c, d, rec.ymin, rec.ymax, rec.closed != 0, emit); });
     });
-    if constexpr (CHAIN) walk_chained(S, ro, rd, per);
+}
+template <typename R, bool CHAIN, typename Keep, typename Per>
+RT_DEV void walk_scene_primary(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> ro, V3<R> rd, const Keep &keep, Per &&per)
+{
+    const uint32_t *const order = Keep::clustered ? P.grp_order : nullptr;
+    walk_primary_tables<R, CHAIN>(S, P, ro, rd, [&](auto recs, uint32_t n, uint32_t slot0, uint32_t shape, auto &&body) {
+        walk_table(recs, n, slot0, S.cl_off[shape], S.grp_off[shape], keep, body, 0xffffffffu, order ? order + S.grp_off[shape] : nullptr);
+    }, [&](auto &&run) { run(); }, per);
+}
+// The camera rays of a whole wave (beam_walk_table); every lane calls this, `valid`: it holds a ray.
+template <typename R, bool CHAIN, typename Per>
+RT_DEV void walk_scene_primary_beam(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> ro, V3<R> rd, bool valid, const R *best, Per &&per)
+{
+    const CullRay<R> cr = cull_ray<R, false>(S, ro, rd);
+    const bool live = valid && !cr.dead;
+    const bool any = __ballot(live) != 0ull;
+    Beam<R> beam = {};
+    if (any) beam = make_beam(cr.u, live);
+    walk_primary_tables<R, CHAIN>(S, P, ro, rd, [&](auto recs, uint32_t n, uint32_t slot0, uint32_t shape, auto &&body) {
+        if (any) beam_walk_table(recs, n, slot0, S.cl_off[shape], S.grp_off[shape], P.grp_order + S.grp_off[shape], P, beam, cr.u, cr.dlen, live, best, body);
+    }, [&](auto &&run) { if (valid) run(); }, per);
 }
 
 // Fill the primary-ray table entry of one slot from the scene tables and the camera origin.
@@ -1317,6 +1458,14 @@ RT_DEV Hit<R> closest_hit_primary(const SceneDev<R> &S, const PrimScene<R> &P, V
     } else {
         return closest_hit_with<R, TRACK>(S, [&](const R *, auto &&per) { walk_scene_primary<R, CHAIN>(S, P, ro, rd, KeepAll(), per); });
     }
+}
+
+// The same for the 64 camera rays of a wave at once, in scenes with the sphere hierarchy and no
+// container bookkeeping.  Called by every lane of the wave; `valid`: this lane holds a ray.
+template <typename R, bool CHAIN>
+RT_DEV Hit<R> closest_hit_primary_beam(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> ro, V3<R> rd, bool valid)
+{
+    return closest_hit_with<R, false>(S, [&](const R *best, auto &&per) { walk_scene_primary_beam<R, CHAIN>(S, P, ro, rd, valid, best, per); });
 }
 
 // src/scenes/world.rs:146-158.  shadowed iff the closest hit (t >= 0) lies before the light

@@ -129,12 +129,22 @@ RT_DEV void primary_ray(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> ro, V
     nd.has_reflect = nd.has_refract = false;
     nd.lighting = { R(0), R(0), R(0) };
     const uint32_t sub = blockIdx.x & out_q.sub_mask;
+    auto children = [&](const Node<R> &c) {
+        if constexpr ((SF & (SF_REFLECTIVE | SF_TRANSPARENT)) != 0)
+            queue_push2(out_q, sub, c.has_reflect, c.over_point, c.reflectv, c.reflect_factor, c.has_refract, c.under_point,
+                        c.refract_dir, c.refract_factor, k);
+    };
+    // camera rays of a scene with the sphere hierarchy: the wave finds its closest hits together
+    constexpr bool kBeam = CAM && (SF & SF_CULL) != 0 && (SF & SF_TRANSPARENT) == 0 && kBeamWalk;
+    Hit<R> beam_hit;
+    if constexpr (kBeam) {
+        RTX_PHASE_BEGIN();
+        beam_hit = closest_hit_primary_beam<R, (SF & SF_CHAIN) != 0>(S, P, ro, rd, valid);
+        RTX_PHASE_MARK(8);
+    }
     if (valid) {
-        nd = trace_node<R, SF, CAM, WALK_WAVE>(S, CAM ? &P : nullptr, ro, rd, remaining, [&](const Node<R> &c) {
-            if constexpr ((SF & (SF_REFLECTIVE | SF_TRANSPARENT)) != 0)
-                queue_push2(out_q, sub, c.has_reflect, c.over_point, c.reflectv, c.reflect_factor, c.has_refract, c.under_point,
-                            c.refract_dir, c.refract_factor, k);
-        });
+        if constexpr (kBeam) nd = shade_node<R, SF, CAM, WALK_WAVE, false>(S, ro, rd, remaining, beam_hit, children);
+        else nd = trace_node<R, SF, CAM, WALK_WAVE>(S, CAM ? &P : nullptr, ro, rd, remaining, children);
         if constexpr (!OUT8) {
             R *px = static_cast<R *>(fb) + (size_t)k * 3;
             px[0] = nd.lighting.x;

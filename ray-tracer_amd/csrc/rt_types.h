@@ -119,14 +119,17 @@ struct alignas(sizeof(R) * 2) PrimCappedRec {
     uint32_t pad[(2 * sizeof(R) - 4) / 4];
 };
 // Bounding sphere of an object, cluster or group as the camera sees it: the tests of a primary ray
-// against it need the centre relative to the camera and three numbers made from the distance and the
-// radius, all the same for every pixel (make_primary_bound fills them, may_hit_primary reads them).
+// against it need the centre relative to the camera and a few numbers made from the distance and
+// the radius, all the same for every pixel (make_primary_bound fills them; may_hit_primary reads the
+// first six for one ray, beam_may_hit all of them for the rays of a whole wave).
 template <typename R>
 struct alignas(sizeof(R) * 2) PrimBoundRec {
     R m[3];    // centre - camera origin
     R k;       // (1 - allowance) * |m|^2 - r^2: the line misses the sphere when k - (m.u)^2 > 0
     R r;       // radius (+inf: unbounded)
     R behind;  // the sphere lies behind the camera when m.u < behind: 0 with the camera outside it, else -inf
+    R km;      // (1 - 4 allowance) * |m|^2: km - (m.a)^2 is a lower bound of the squared distance of the centre from axis a
+    R dist;    // a lower bound of |m|
 };
 template <typename R>
 struct PrimScene {
@@ -228,6 +231,11 @@ struct QueueDev {
 #define RTX_SPREAD_LANES (1024u * 4u * 64u)
 #endif
 constexpr uint32_t kSpreadLanes = RTX_SPREAD_LANES;
+// camera rays of scenes with the sphere hierarchy are walked a wave at a time (beam_walk_table)
+#ifndef RTX_BEAM_WALK
+#define RTX_BEAM_WALK 1
+#endif
+constexpr bool kBeamWalk = RTX_BEAM_WALK != 0;
 constexpr int kStatShards = 256;
 struct StatShard {
     unsigned long long hits[8];  // shaded hits (= is_shadowed calls) per recursion level
