@@ -692,13 +692,13 @@ struct SphereCull {
 // The origin is not moved towards the scene here (CullRay::shift is ignored): all of it is
 // relative to the camera itself.
 template <typename R>
-RT_DEV void make_primary_bound(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> cam_origin, uint32_t i)
+RT_DEV void make_primary_bound(const SceneDev<R> &S, const ApexBounds<R> &to, V3<R> cam_origin, uint32_t i)
 {
     const BoundRec<R> *src;
     PrimBoundRec<R> *dst;
-    if (i < S.n_bnd_total) { src = S.bnd + i; dst = const_cast<PrimBoundRec<R> *>(P.bnd) + i; }
-    else if ((i -= S.n_bnd_total) < S.n_cl_total) { src = S.cl + i; dst = const_cast<PrimBoundRec<R> *>(P.cl) + i; }
-    else if ((i -= S.n_cl_total) < S.n_grp_total) { src = S.grp + i; dst = const_cast<PrimBoundRec<R> *>(P.grp) + i; }
+    if (i < S.n_bnd_total) { src = S.bnd + i; dst = const_cast<PrimBoundRec<R> *>(to.bnd) + i; }
+    else if ((i -= S.n_bnd_total) < S.n_cl_total) { src = S.cl + i; dst = const_cast<PrimBoundRec<R> *>(to.cl) + i; }
+    else if ((i -= S.n_cl_total) < S.n_grp_total) { src = S.grp + i; dst = const_cast<PrimBoundRec<R> *>(to.grp) + i; }
     else return;
     const BoundRec<R> b = *src;
     PrimBoundRec<R> out;
@@ -934,11 +934,38 @@ RT_DEV bool beam_may_hit(const PrimBoundRec<R> &b, const Beam<R> &bm, R reach_ma
     const R far = (b.dist - b.r) - reach_max;
     return !(Num<R>::max_(Num<R>::max_(miss, behind), far) > R(0));
 }
-// group_order: the table's groups nearest first (table-relative indices); u, dlen, best: this lane's ray
-// (unit direction, |direction|, closest hit so far), live as for make_beam.  All 64 lanes call this.
-template <typename R, typename Rec, typename Body>
+// What the lanes bring to a beam walk, for camera rays: the lane's own ray (unit direction, |direction|,
+// closest hit so far).  reach(): how far from the apex this lane still looks (-inf: it does not),
+// test(slot): whether its ray may hit the object at `slot`, with the test of that one ray.
+template <typename R>
+struct CameraLane {
+    const PrimBoundRec<R> *bnd;
+    V3<R> u;
+    R dlen;
+    bool live;
+    const R *best;
+    RT_DEV R reach() const { return live ? *best * dlen : -Num<R>::inf; }
+    RT_DEV bool test(uint32_t slot) const { return live & may_hit_primary<R, false>(PrimSphereCull<R, false>::head(bnd + slot), u, *best * dlen); }
+};
+// For the shadow rays of a wave's hits, which all end at the light: the cone has its apex THERE
+// and holds the directions from the light to the hit points; a lane looks as far from the light as
+// its hit point lies, until its ray is known to be blocked.
+template <typename R>
+struct ShadowLane {
+    const BoundRec<R> *bnd;
+    CullRay<R> cr;  // the shadow ray itself, hit point to light
+    R distance;     // of the light along it
+    bool live;
+    const bool *shadowed;
+    RT_DEV bool open() const { return live && !*shadowed; }
+    RT_DEV R reach() const { return open() ? distance * cr.dlen : -Num<R>::inf; }
+    RT_DEV bool test(uint32_t slot) const { return open() & may_hit<R, false>(load_uniform(bnd + slot), cr, distance * cr.dlen - cr.shift); }
+};
+// group_order: the table's groups in the order to meet them (table-relative indices) or null for table
+// order; from: the spheres relative to the apex.  All 64 lanes call this.
+template <typename R, typename Rec, typename Lane, typename Body>
 RT_DEV void beam_walk_table(const Rec *recs, uint32_t n, uint32_t slot0, uint32_t cluster0, uint32_t group0, const uint32_t *group_order,
-                            const PrimScene<R> &P, const Beam<R> &beam, V3<R> u, R dlen, bool live, const R *best, Body &&body)
+                            const ApexBounds<R> &from, const Beam<R> &beam, const Lane &ray, Body &&body)
 {
     static_assert(kCluster == 16, "a quarter of the wave per cluster");
     if (n == 0u) return;
@@ -946,15 +973,15 @@ RT_DEV void beam_walk_table(const Rec *recs, uint32_t n, uint32_t slot0, uint32_
     const uint32_t quarter = lane >> 4, member = lane & 15u;
     const uint32_t n_cl = (n + kCluster - 1) / kCluster, n_grp = (n_cl + kCluster - 1) / kCluster;
     auto mine = [&](const uint32_t v[4]) { return quarter == 0u ? v[0] : quarter == 1u ? v[1] : quarter == 2u ? v[2] : v[3]; };
-    auto larger = [](R x, R y) { return Num<R>::max_(x, y); };
-    auto wave_reach = [&]() { return wave_reduce(live ? *best * dlen : -Num<R>::inf, larger); };
+    auto wave_reach = [&]() { return wave_reduce(ray.reach(), [](R x, R y) { return Num<R>::max_(x, y); }); };
     R reach_max = wave_reach();
     for (uint32_t g0 = 0; g0 < n_grp; g0 += 64u) {
+        if (!(reach_max > -Num<R>::inf)) return;  // no lane is looking any more
         bool hit_g = false;
         uint32_t g_rel = 0u;
         if (g0 + lane < n_grp) {
-            g_rel = group_order[g0 + lane];
-            hit_g = beam_may_hit(P.grp[group0 + g_rel], beam, reach_max);
+            g_rel = group_order ? group_order[g0 + lane] : g0 + lane;
+            hit_g = beam_may_hit(from.grp[group0 + g_rel], beam, reach_max);
         }
         unsigned long long groups = __ballot(hit_g);
         while (groups != 0ull) {
@@ -963,7 +990,7 @@ RT_DEV void beam_walk_table(const Rec *recs, uint32_t n, uint32_t slot0, uint32_
             for (int j = 0; j < 4; ++j) gidx[j] = (uint32_t)__builtin_amdgcn_readlane((int)g_rel, (int)gpos[j]);
             const uint32_t c = mine(gidx) * kCluster + member;
             bool hit_c = false;
-            if (quarter < n_g && c < n_cl) hit_c = beam_may_hit(P.cl[cluster0 + c], beam, reach_max);
+            if (quarter < n_g && c < n_cl) hit_c = beam_may_hit(from.cl[cluster0 + c], beam, reach_max);
             unsigned long long clusters = __ballot(hit_c);
             while (clusters != 0ull) {
                 uint32_t cpos[4], cidx[4];
@@ -971,20 +998,20 @@ RT_DEV void beam_walk_table(const Rec *recs, uint32_t n, uint32_t slot0, uint32_
                 for (int j = 0; j < 4; ++j) cidx[j] = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)cpos[j]);
                 const uint32_t i = mine(cidx) * kCluster + member;
                 bool hit_o = false;
-                if (quarter < n_c && i < n) hit_o = beam_may_hit(P.bnd[slot0 + i], beam, reach_max);
+                if (quarter < n_c && i < n) hit_o = beam_may_hit(from.bnd[slot0 + i], beam, reach_max);
                 unsigned long long objects = __ballot(hit_o);
                 if (objects == 0ull) continue;
                 while (objects != 0ull) {
                     const uint32_t at = (uint32_t)__builtin_ctzll(objects);
                     objects &= objects - 1ull;
                     const uint32_t io = (uint32_t)__builtin_amdgcn_readlane((int)i, (int)at);
-                    const PrimBoundHead<R> b = PrimSphereCull<R, false>::head(P.bnd + slot0 + io);
-                    const bool mine_too = live & may_hit_primary<R, false>(b, u, *best * dlen);
+                    const bool mine_too = ray.test(slot0 + io);
                     if (__ballot(mine_too) == 0ull) continue;
                     const Rec rec = load_uniform(recs + io);
                     if (mine_too) body(rec, slot0 + io);
                 }
                 reach_max = wave_reach();
+                if (!(reach_max > -Num<R>::inf)) return;
             }
         }
     }
@@ -1024,6 +1051,67 @@ RT_DEV void walk_chained(const SceneDev<R> &S, V3<R> ro, V3<R> rd, Per &&per)
             }
         });
     }
+}
+
+// The five tables and the chained objects with a wave-uniform slot: `bounded(recs, n, slot0, shape,
+// body)` walks a table whose objects have finite bounding spheres, `unbounded(...)` one of the other
+// two (planes, cones); body(rec, slot) takes the ray into the object's space and intersects.
+// UNBOUNDED_FIRST: planes and cones before the rest (what is found there shortens the other walks).
+template <typename R, bool CHAIN, bool UNBOUNDED_FIRST, typename Bounded, typename Unbounded, typename Per>
+RT_DEV void walk_scene_tables(const SceneDev<R> &S, V3<R> ro, V3<R> rd, Bounded &&bounded, Unbounded &&unbounded, Per &&per)
+{
+    // the ray in the space of the object at `slot` (wave-uniform branch: the flag is a scalar)
+    auto into_object = [&](const R *m, uint32_t slot, V3<R> &o, V3<R> &d) {
+        if (ro_load(S.slot_flags + slot) & SLOT_DIAGONAL) {
+            o = diag_point(m, ro);
+            d = diag_vector(m, rd);
+        } else {
+            o = xform_point(m, ro);
+            d = xform_vector(m, rd);
+        }
+    };
+    auto planes = [&]() {
+        unbounded(S.pln, S.n_pln, S.n_sph, (uint32_t)SH_PLANE, [&](const PlaneRec<R> &rec, uint32_t slot) {
+            // only the y row of the object-space ray is read by planes.rs:11-17
+            R oy, dy;
+            if (ro_load(S.slot_flags + slot) & SLOT_DIAGONAL) {
+                oy = rec.m[1] * ro.y + rec.m[3];
+                dy = rec.m[1] * rd.y;
+            } else {
+                oy = ((rec.m[0] * ro.x + rec.m[1] * ro.y) + rec.m[2] * ro.z) + rec.m[3];
+                dy = (rec.m[0] * rd.x + rec.m[1] * rd.y) + rec.m[2] * rd.z;
+            }
+            per(slot, [&](auto &&emit) { isect_plane(-oy, dy, emit); });
+        });
+    };
+    auto cones = [&]() {
+        unbounded(S.con, S.n_con, S.n_sph + S.n_pln + S.n_cub + S.n_cyl, (uint32_t)SH_CONE, [&](const CappedRec<R> &rec, uint32_t slot) {
+            V3<R> o, d;
+            into_object(rec.m, slot, o, d);
+            per(slot, [&](auto &&emit) { isect_cone(o, twice(o), cone_c(o), d, rec.ymin, rec.ymax, rec.closed != 0, emit); });
+        });
+    };
+    if constexpr (UNBOUNDED_FIRST) { planes(); cones(); }
+    bounded(S.sph, S.n_sph, 0u, (uint32_t)SH_SPHERE, [&](const XformRec<R> &rec, uint32_t slot) {
+        V3<R> o, d;
+        into_object(rec.m, slot, o, d);
+        per(slot, [&](auto &&emit) { isect_sphere(o, d, sphere_c(o), emit); });
+    });
+    if constexpr (!UNBOUNDED_FIRST) planes();
+    bounded(S.cub, S.n_cub, S.n_sph + S.n_pln, (uint32_t)SH_CUBE, [&](const XformRec<R> &rec, uint32_t slot) {
+        V3<R> o, d;
+        into_object(rec.m, slot, o, d);
+        const V3<R> lo = { R(-1) - o.x, R(-1) - o.y, R(-1) - o.z };
+        const V3<R> hi = { R(1) - o.x, R(1) - o.y, R(1) - o.z };
+        per(slot, [&](auto &&emit) { isect_cube(lo, hi, d, emit); });
+    });
+    bounded(S.cyl, S.n_cyl, S.n_sph + S.n_pln + S.n_cub, (uint32_t)SH_CYLINDER, [&](const CappedRec<R> &rec, uint32_t slot) {
+        V3<R> o, d;
+        into_object(rec.m, slot, o, d);
+        per(slot, [&](auto &&emit) { isect_cylinder(o, twice(o), cylinder_c(o), d, rec.ymin, rec.ymax, rec.closed != 0, emit); });
+    });
+    if constexpr (!UNBOUNDED_FIRST) cones();
+    if constexpr (CHAIN) walk_chained(S, ro, rd, per);
 }
 
 // `table(recs, n, slot0, cluster0, group0, body)`: one table, walked wave by wave, lane by lane, or by
@@ -1072,64 +1160,19 @@ RT_DEV void walk_scene(const SceneDev<R> &S, V3<R> ro, V3<R> rd, const Keep &kee
         if constexpr (CHAIN) walk_chained(S, ro, rd, per);
         return;
     }
-    uint32_t slot0 = 0;
 #ifdef RTX_LDS_TABLES
     const LdsOffsets<R> lo_ = lds_offsets(S);
     constexpr bool kLds = !Keep::clustered;
-#define RTX_LDS_ARG(f) , (kLds ? lo_.f : 0xffffffffu)
+    const uint32_t lds_at[5] = { kLds ? lo_.sph : 0xffffffffu, kLds ? lo_.pln : 0xffffffffu, kLds ? lo_.cub : 0xffffffffu,
+                                 kLds ? lo_.cyl : 0xffffffffu, kLds ? lo_.con : 0xffffffffu };
 #else
-#define RTX_LDS_ARG(f)
+    const uint32_t lds_at[5] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu };
 #endif
-    // the ray in the space of the object at `slot` (wave-uniform branch: the flag is a scalar)
-    auto into_object = [&](const R *m, uint32_t slot, V3<R> &o, V3<R> &d) {
-        if (ro_load(S.slot_flags + slot) & SLOT_DIAGONAL) {
-            o = diag_point(m, ro);
-            d = diag_vector(m, rd);
-        } else {
-            o = xform_point(m, ro);
-            d = xform_vector(m, rd);
-        }
-    };
-    walk_table(S.sph, S.n_sph, slot0, S.cl_off[SH_SPHERE], S.grp_off[SH_SPHERE], keep, [&](const XformRec<R> &rec, uint32_t slot) {
-        V3<R> o, d;
-        into_object(rec.m, slot, o, d);
-        per(slot, [&](auto &&emit) { isect_sphere(o, d, sphere_c(o), emit); });
-    } RTX_LDS_ARG(sph));
-    slot0 += S.n_sph;
-    walk_table(S.pln, S.n_pln, slot0, 0u, 0u, KeepAll(), [&](const PlaneRec<R> &rec, uint32_t slot) {
-        // only the y row of the object-space ray is read by planes.rs:11-17
-        R oy, dy;
-        if (ro_load(S.slot_flags + slot) & SLOT_DIAGONAL) {
-            oy = rec.m[1] * ro.y + rec.m[3];
-            dy = rec.m[1] * rd.y;
-        } else {
-            oy = ((rec.m[0] * ro.x + rec.m[1] * ro.y) + rec.m[2] * ro.z) + rec.m[3];
-            dy = (rec.m[0] * rd.x + rec.m[1] * rd.y) + rec.m[2] * rd.z;
-        }
-        per(slot, [&](auto &&emit) { isect_plane(-oy, dy, emit); });
-    } RTX_LDS_ARG(pln));
-    slot0 += S.n_pln;
-    walk_table(S.cub, S.n_cub, slot0, S.cl_off[SH_CUBE], S.grp_off[SH_CUBE], keep, [&](const XformRec<R> &rec, uint32_t slot) {
-        V3<R> o, d;
-        into_object(rec.m, slot, o, d);
-        const V3<R> lo = { R(-1) - o.x, R(-1) - o.y, R(-1) - o.z };
-        const V3<R> hi = { R(1) - o.x, R(1) - o.y, R(1) - o.z };
-        per(slot, [&](auto &&emit) { isect_cube(lo, hi, d, emit); });
-    } RTX_LDS_ARG(cub));
-    slot0 += S.n_cub;
-    walk_table(S.cyl, S.n_cyl, slot0, S.cl_off[SH_CYLINDER], S.grp_off[SH_CYLINDER], keep, [&](const CappedRec<R> &rec, uint32_t slot) {
-        V3<R> o, d;
-        into_object(rec.m, slot, o, d);
-        per(slot, [&](auto &&emit) { isect_cylinder(o, twice(o), cylinder_c(o), d, rec.ymin, rec.ymax, rec.closed != 0, emit); });
-    } RTX_LDS_ARG(cyl));
-    slot0 += S.n_cyl;
-    walk_table(S.con, S.n_con, slot0, 0u, 0u, KeepAll(), [&](const CappedRec<R> &rec, uint32_t slot) {
-        V3<R> o, d;
-        into_object(rec.m, slot, o, d);
-        per(slot, [&](auto &&emit) { isect_cone(o, twice(o), cone_c(o), d, rec.ymin, rec.ymax, rec.closed != 0, emit); });
-    } RTX_LDS_ARG(con));
-#undef RTX_LDS_ARG
-    if constexpr (CHAIN) walk_chained(S, ro, rd, per);
+    walk_scene_tables<R, CHAIN, false>(S, ro, rd, [&](auto recs, uint32_t n, uint32_t slot0, uint32_t shape, auto &&body) {
+        walk_table(recs, n, slot0, S.cl_off[shape], S.grp_off[shape], keep, body, lds_at[shape]);
+    }, [&](auto recs, uint32_t n, uint32_t slot0, uint32_t shape, auto &&body) {
+        walk_table(recs, n, slot0, 0u, 0u, KeepAll(), body, lds_at[shape]);
+    }, per);
 }
 
 // The same walk for primary rays: they all start at the camera, so the object-space origin
@@ -1198,12 +1241,12 @@ template <typename R, bool CHAIN, typename Per>
 RT_DEV void walk_scene_primary_beam(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> ro, V3<R> rd, bool valid, const R *best, Per &&per)
 {
     const CullRay<R> cr = cull_ray<R, false>(S, ro, rd);
-    const bool live = valid && !cr.dead;
-    const bool any = __ballot(live) != 0ull;
+    const CameraLane<R> ray = { P.eye.bnd, cr.u, cr.dlen, valid && !cr.dead, best };
+    const bool any = __ballot(ray.live) != 0ull;
     Beam<R> beam = {};
-    if (any) beam = make_beam(cr.u, live);
+    if (any) beam = make_beam(cr.u, ray.live);
     walk_primary_tables<R, CHAIN>(S, P, ro, rd, [&](auto recs, uint32_t n, uint32_t slot0, uint32_t shape, auto &&body) {
-        if (any) beam_walk_table(recs, n, slot0, S.cl_off[shape], S.grp_off[shape], P.grp_order + S.grp_off[shape], P, beam, cr.u, cr.dlen, live, best, body);
+        if (any) beam_walk_table(recs, n, slot0, S.cl_off[shape], S.grp_off[shape], P.grp_order + S.grp_off[shape], P.eye, beam, ray, body);
     }, [&](auto &&run) { if (valid) run(); }, per);
 }
 
@@ -1452,7 +1495,7 @@ RT_DEV Hit<R> closest_hit_primary(const SceneDev<R> &S, const PrimScene<R> &P, V
     if constexpr (CULL) {
         return closest_hit_with<R, TRACK>(S, [&](const R *best, auto &&per) {
             const CullRay<R> cr = cull_ray<R, TRACK>(S, ro, rd);
-            const PrimSphereCull<R, TRACK> keep = { P.bnd, P.cl, P.grp, cr.u, cr.dlen, cr.dead, best };
+            const PrimSphereCull<R, TRACK> keep = { P.eye.bnd, P.eye.cl, P.eye.grp, cr.u, cr.dlen, cr.dead, best };
             walk_scene_primary<R, CHAIN>(S, P, ro, rd, keep, per);
         });
     } else {
@@ -1496,6 +1539,44 @@ RT_DEV bool is_shadowed(const SceneDev<R> &S, V3<R> p, V3<R> dir, R distance)
         if (h.slot == kNone) return false;
         return h.t < distance && (ColdTable<R, COLD_LDS>::base(S)[h.obj].flags & OF_CASTS_SHADOW) != 0;
     }
+}
+
+// is_shadowed for the hits of a wave of camera rays, in scenes with the sphere hierarchy in which
+// every object casts a shadow: their shadow rays end at one point, the light, so the wave walks the
+// hierarchy once with a cone from the light around the hit points (beam_walk_table, ShadowLane).
+// The rays tested exactly are the reference's, hit point to light.  Called by every lane;
+// `asks`: this lane has a hit to shade.
+template <typename R, uint32_t SF>
+RT_DEV bool is_shadowed_beam(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> p, V3<R> dir, R distance, bool asks)
+{
+    static_assert((SF & SF_ALL_CAST) != 0 && (SF & SF_CULL) != 0, "any-hit shadows over the hierarchy");
+    constexpr bool CHAIN = (SF & SF_CHAIN) != 0;
+    bool shadowed = false;
+    auto per = [&](uint32_t, auto &&run) {
+        run([&](R t, bool ok = true) {
+            if (ok && t >= R(0) && t < distance) shadowed = true;
+        });
+    };
+    const CullRay<R> cr = cull_ray<R, false>(S, p, dir);
+    const ShadowLane<R> ray = { S.bnd, cr, distance, asks && !cr.dead, &shadowed };
+    Beam<R> beam = {};
+    const bool any = __ballot(ray.live) != 0ull;
+    if (any) beam = make_beam<R>({ -cr.u.x, -cr.u.y, -cr.u.z }, ray.live);
+    if (any && !(beam.sin_w < P.shadow_beam_sin)) {
+        // Hit points spread in depth (a tile across the edge of an object) are far apart as the light
+        // sees them; the cone then holds much of the scene and the rays are better off on their own.
+        if (asks) {
+            const SphereCull<R, false> keep = { S.bnd, S.cl, S.grp, cr, nullptr, distance, &shadowed };
+            walk_scene<R, CHAIN, WALK_WAVE>(S, p, dir, keep, per);
+        }
+        return shadowed;
+    }
+    walk_scene_tables<R, CHAIN, true>(S, p, dir, [&](auto recs, uint32_t n, uint32_t slot0, uint32_t shape, auto &&body) {
+        if (any) beam_walk_table(recs, n, slot0, S.cl_off[shape], S.grp_off[shape], (const uint32_t *)nullptr, P.light, beam, ray, body);
+    }, [&](auto recs, uint32_t n, uint32_t slot0, uint32_t, auto &&body) {
+        if (asks && !shadowed) walk_table(recs, n, slot0, 0u, 0u, KeepAll(), body);
+    }, [&](uint32_t slot, auto &&run) { if (asks) per(slot, run); });
+    return shadowed;
 }
 
 // per-shape normals: spheres.rs:20-22, planes.rs:7-9, cubes.rs:53-63, cylinders.rs:96-105,
@@ -1622,8 +1703,17 @@ RT_DEV Node<R> trace_node(const SceneDev<R> &S, const PrimScene<R> *P, V3<R> ro,
     return shade_node<R, SF, PRIMARY, WALK, COLD_LDS>(S, ro, rd, remaining, h, children);
 }
 
-template <typename R, uint32_t SF, bool PRIMARY, int WALK, bool COLD_LDS, typename Children>
-RT_DEV Node<R> shade_node(const SceneDev<R> &S, V3<R> ro, V3<R> rd, uint32_t remaining, const Hit<R> &h, Children &&children)
+// shade_node in two parts, so that a kernel can answer the shadow queries of a whole wave between
+// them: everything up to the shadow ray (which is returned: hit point to light, unit direction,
+// distance of the light), and the lighting once it is known whether the point is shadowed.
+template <typename R>
+struct ShadowQuery {
+    V3<R> lightv;
+    R ldist;
+};
+template <typename R, uint32_t SF, bool PRIMARY, bool COLD_LDS, typename Children>
+RT_DEV Node<R> shade_prepare(const SceneDev<R> &S, V3<R> ro, V3<R> rd, uint32_t remaining, const Hit<R> &h, ShadowQuery<R> &query,
+                             Children &&children)
 {
     constexpr bool TRACK = (SF & SF_TRANSPARENT) != 0;
     Node<R> nd;
@@ -1683,7 +1773,7 @@ RT_DEV Node<R> shade_node(const SceneDev<R> &S, V3<R> ro, V3<R> rd, uint32_t rem
     nd.inside = inside; nd.n1 = n1; nd.n2 = n2;
 
     // reflected_color, world.rs:160-173
-    R reflective = R(0), transparency = R(0);
+    [[maybe_unused]] R reflective = R(0), transparency = R(0);
     if constexpr ((SF & SF_REFLECTIVE) != 0) {
         reflective = cold.reflective;
         if (remaining >= 1 && reflective != R(0)) {
@@ -1741,12 +1831,18 @@ RT_DEV Node<R> shade_node(const SceneDev<R> &S, V3<R> ro, V3<R> rd, uint32_t rem
     // shade_hit, world.rs:121-123.  is_shadowed (world.rs:146-150) and lighting (lights.rs:49)
     // both normalise light.position - over_point; the vector is formed once here.
     V3<R> lvec = { S.light_pos[0] - over.x, S.light_pos[1] - over.y, S.light_pos[2] - over.z };
-    R ldist;
-    V3<R> lightv = normalized(lvec, (lvec.x * lvec.x + lvec.y * lvec.y) + lvec.z * lvec.z, &ldist);
-    bool shadowed = is_shadowed<R, SF, WALK, COLD_LDS>(S, over, lightv, ldist);
-    nd.shadowed = shadowed;
-    RTX_PHASE_MARK(PRIMARY ? 11 : 3);
+    query.lightv = normalized(lvec, (lvec.x * lvec.x + lvec.y * lvec.y) + lvec.z * lvec.z, &query.ldist);
+    return nd;
+}
 
+template <typename R, uint32_t SF, bool PRIMARY, bool COLD_LDS>
+RT_DEV void shade_finish(const SceneDev<R> &S, V3<R> rd, Node<R> &nd, const ShadowQuery<R> &query, bool shadowed)
+{
+    typename ColdTable<R, COLD_LDS>::Rec &cold = ColdTable<R, COLD_LDS>::base(S)[nd.obj];
+    const V3<R> eyev = { -rd.x, -rd.y, -rd.z };
+    const V3<R> over = nd.over_point, normalv = nd.normalv, lightv = query.lightv;
+    nd.shadowed = shadowed;
+    RTX_PHASE_BEGIN();
     // lighting, lights.rs:43-78, evaluated at over_point
     V3<R> clr = { cold.color[0], cold.color[1], cold.color[2] };
     if constexpr ((SF & SF_PATTERN) != 0) {
@@ -1779,9 +1875,22 @@ RT_DEV Node<R> shade_node(const SceneDev<R> &S, V3<R> ro, V3<R> rd, uint32_t rem
     }
     nd.lighting = result;
     RTX_PHASE_MARK(PRIMARY ? 12 : 4);
+}
 
+template <typename R, uint32_t SF, bool PRIMARY, int WALK, bool COLD_LDS, typename Children>
+RT_DEV Node<R> shade_node(const SceneDev<R> &S, V3<R> ro, V3<R> rd, uint32_t remaining, const Hit<R> &h, Children &&children)
+{
+    ShadowQuery<R> query;
+    Node<R> nd = shade_prepare<R, SF, PRIMARY, COLD_LDS>(S, ro, rd, remaining, h, query, children);
+    if (!nd.hit) return nd;
+    RTX_PHASE_BEGIN();
+    const bool shadowed = is_shadowed<R, SF, WALK, COLD_LDS>(S, nd.over_point, query.lightv, query.ldist);
+    RTX_PHASE_MARK(PRIMARY ? 11 : 3);
+    shade_finish<R, SF, PRIMARY, COLD_LDS>(S, rd, nd, query, shadowed);
     return nd;
 }
+
+
 
 // src/scenes/camera.rs:147-158
 template <typename R>

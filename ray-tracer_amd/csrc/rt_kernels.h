@@ -134,17 +134,25 @@ RT_DEV void primary_ray(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> ro, V
             queue_push2(out_q, sub, c.has_reflect, c.over_point, c.reflectv, c.reflect_factor, c.has_refract, c.under_point,
                         c.refract_dir, c.refract_factor, k);
     };
-    // camera rays of a scene with the sphere hierarchy: the wave finds its closest hits together
+    // camera rays of a scene with the sphere hierarchy: the wave finds its closest hits together, and
+    // then whether they are shadowed (shadow rays all end at the light)
     constexpr bool kBeam = CAM && (SF & SF_CULL) != 0 && (SF & SF_TRANSPARENT) == 0 && kBeamWalk;
-    Hit<R> beam_hit;
     if constexpr (kBeam) {
         RTX_PHASE_BEGIN();
-        beam_hit = closest_hit_primary_beam<R, (SF & SF_CHAIN) != 0>(S, P, ro, rd, valid);
+        const Hit<R> h = closest_hit_primary_beam<R, (SF & SF_CHAIN) != 0>(S, P, ro, rd, valid);
         RTX_PHASE_MARK(8);
+        ShadowQuery<R> query = { { R(0), R(0), R(0) }, R(0) };
+        nd.over_point = { R(0), R(0), R(0) };
+        if (valid) nd = shade_prepare<R, SF, CAM, false>(S, ro, rd, remaining, h, query, children);
+        const bool asks = valid && nd.hit;
+        bool shadowed = false;
+        if constexpr ((SF & SF_ALL_CAST) != 0) shadowed = is_shadowed_beam<R, SF>(S, P, nd.over_point, query.lightv, query.ldist, asks);
+        else if (asks) shadowed = is_shadowed<R, SF, WALK_WAVE, false>(S, nd.over_point, query.lightv, query.ldist);
+        RTX_PHASE_MARK(11);
+        if (asks) shade_finish<R, SF, CAM, false>(S, rd, nd, query, shadowed);
     }
     if (valid) {
-        if constexpr (kBeam) nd = shade_node<R, SF, CAM, WALK_WAVE, false>(S, ro, rd, remaining, beam_hit, children);
-        else nd = trace_node<R, SF, CAM, WALK_WAVE>(S, CAM ? &P : nullptr, ro, rd, remaining, children);
+        if constexpr (!kBeam) nd = trace_node<R, SF, CAM, WALK_WAVE>(S, CAM ? &P : nullptr, ro, rd, remaining, children);
         if constexpr (!OUT8) {
             R *px = static_cast<R *>(fb) + (size_t)k * 3;
             px[0] = nd.lighting.x;
@@ -233,7 +241,10 @@ k_frame_begin(CameraDev<R> cam, SceneDev<R> S, PrimScene<R> P, uint32_t n_tables
     if (i < n_b) zero_b[i] = 0u;
     if (i < n_tables) make_primary_record<R>(S, P, { cam.origin[0], cam.origin[1], cam.origin[2] }, i);
     if (n_tables != 0u && i < S.n_grp_total) rank_group<R>(S, P, { cam.origin[0], cam.origin[1], cam.origin[2] }, i);
-    if (n_tables != 0u && P.bnd) make_primary_bound<R>(S, P, { cam.origin[0], cam.origin[1], cam.origin[2] }, i);
+    if (n_tables != 0u && P.eye.bnd) {
+        make_primary_bound<R>(S, P.eye, { cam.origin[0], cam.origin[1], cam.origin[2] }, i);
+        make_primary_bound<R>(S, P.light, { S.light_pos[0], S.light_pos[1], S.light_pos[2] }, i);
+    }
 }
 
 template <typename R>
@@ -379,7 +390,7 @@ hipError_t Launch<R>::frame_begin(hipStream_t stream, const CameraDev<R> *cam, c
                                   const PrimScene<R> &prim, uint32_t *zero_a, uint32_t n_a, uint32_t *zero_b, uint32_t n_b)
 {
     const uint32_t n_tables = cam ? scene.n : 0u;  // (a scene has fewer groups than objects)
-    const uint32_t n_bounds = (cam && prim.bnd) ? scene.n_bnd_total + scene.n_cl_total + scene.n_grp_total : 0u;
+    const uint32_t n_bounds = (cam && prim.eye.bnd) ? scene.n_bnd_total + scene.n_cl_total + scene.n_grp_total : 0u;
     uint32_t n = n_tables > n_a ? (n_tables > n_b ? n_tables : n_b) : (n_a > n_b ? n_a : n_b);
     n = n > n_bounds ? n : n_bounds;
     if (n == 0) return hipSuccess;

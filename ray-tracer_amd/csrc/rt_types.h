@@ -131,6 +131,11 @@ struct alignas(sizeof(R) * 2) PrimBoundRec {
     R km;      // (1 - 4 allowance) * |m|^2: km - (m.a)^2 is a lower bound of the squared distance of the centre from axis a
     R dist;    // a lower bound of |m|
 };
+// the spheres of the hierarchy relative to one point (same indices as SceneDev::bnd, cl, grp)
+template <typename R>
+struct ApexBounds {
+    const PrimBoundRec<R> *bnd, *cl, *grp;
+};
 template <typename R>
 struct PrimScene {
     const PrimSphereRec<R> *sph;
@@ -145,7 +150,10 @@ struct PrimScene {
     // the run of shape s starts at SceneDev::grp_off[s]).  Primary rays meet the groups in that order,
     // so that what they hit nearby rules out the groups farther away before those are entered.
     const uint32_t *grp_order;
-    const PrimBoundRec<R> *bnd, *cl, *grp;  // same indices as SceneDev::bnd, cl, grp
+    ApexBounds<R> eye;    // relative to the camera: for the camera rays
+    ApexBounds<R> light;  // relative to the light: for the shadow rays of their hits
+    // the shadow rays of a wave are walked together when the sine of their cone's half-angle is below this
+    R shadow_beam_sin;
 };
 
 // Shading record: read once per shaded hit, gathered per lane by original object index.

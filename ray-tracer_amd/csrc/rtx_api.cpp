@@ -1022,7 +1022,7 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Workspace &ws, hipEv
         const size_t b_pbnd = culled ? pad((size_t)SD.n_bnd_total * sizeof(PrimBoundRec<R>)) : 0,
                      b_pcl = culled ? pad((size_t)SD.n_cl_total * sizeof(PrimBoundRec<R>)) : 0,
                      b_pgrp = culled ? pad((size_t)SD.n_grp_total * sizeof(PrimBoundRec<R>)) : 0;
-        const size_t need = b_sph + b_pln + b_cub + b_cyl + b_con + b_order + b_pbnd + b_pcl + b_pgrp + 256;
+        const size_t need = b_sph + b_pln + b_cub + b_cyl + b_con + b_order + 2 * (b_pbnd + b_pcl + b_pgrp) + 256;
         if (ws.fixed) {
             if (need > ws.prim_bytes)
                 return fail(RTX_ERR_INVALID, "scene too large for the fixed workspace: its primary-ray tables need %zu bytes, it holds %zu",
@@ -1042,10 +1042,16 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Workspace &ws, hipEv
         char *after = base + b_sph + b_pln + b_cub + b_cyl + b_con;
         prim.grp_order = (const uint32_t *)after;
         if (culled) {
-            prim.bnd = (const PrimBoundRec<R> *)(after + b_order);
-            prim.cl = (const PrimBoundRec<R> *)(after + b_order + b_pbnd);
-            prim.grp = (const PrimBoundRec<R> *)(after + b_order + b_pbnd + b_pcl);
+            char *at = after + b_order;
+            for (ApexBounds<R> *set : { &prim.eye, &prim.light }) {
+                set->bnd = (const PrimBoundRec<R> *)at;
+                set->cl = (const PrimBoundRec<R> *)(at + b_pbnd);
+                set->grp = (const PrimBoundRec<R> *)(at + b_pbnd + b_pcl);
+                at += b_pbnd + b_pcl + b_pgrp;
+            }
         }
+        static const double beam_sin = [] { const char *e = std::getenv("RTX_SHADOW_BEAM_SIN"); return e ? std::atof(e) : 0.1; }();
+        prim.shadow_beam_sin = (R)beam_sin;
         prim.n_sph = SD.n_sph; prim.n_pln = SD.n_pln; prim.n_cub = SD.n_cub; prim.n_cyl = SD.n_cyl; prim.n_con = SD.n_con;
     }
     // The first launch of a frame zeroes the queue and hit counters and fills the primary-ray tables.
