@@ -96,13 +96,14 @@ def glass_scene(api, hsize=3840, vsize=2160, n_lights=1):
     return w, cam
 
 
-def random_scene(api, n_objects=10000, hsize=3840, vsize=2160, seed=0xC0FFEE):
+def random_scene(api, n_objects=10000, hsize=3840, vsize=2160, seed=0xC0FFEE, light=(-30.0, 60.0, -40.0), no_shadow_every=0):
     """S4: n random spheres / cubes / closed cylinders plus a checker floor and a striped back
     wall.  Scales stay >= 0.3 so every transform has |det| >= 1e-5 (the reference panics
-    below that, src/matrices/matrix4.rs:100-107)."""
+    below that, src/matrices/matrix4.rs:100-107).  Variants for tests: another light position;
+    every no_shadow_every-th object casting no shadow."""
     rng = SplitMix64(seed)
     w = api.world()
-    for _ in range(n_objects):
+    for index in range(n_objects):
         kind = rng.uniform()
         if kind < 0.5:
             o = api.sphere()
@@ -120,6 +121,8 @@ def random_scene(api, n_objects=10000, hsize=3840, vsize=2160, seed=0xC0FFEE):
         o.set_color(*col)
         if refl:
             o.set_reflective(0.3)
+        if no_shadow_every and index % no_shadow_every == 0:
+            o.set_casts_shadow(False)
         w.add_object(o)
     w.add_object(api.plane().set_pattern(CHECKER3D, (0.85, 0.85, 0.85), (0.2, 0.2, 0.25))
                  .set_pattern_transform(api.m_scaling(2.0, 2.0, 2.0)).set_specular(0.1))
@@ -127,7 +130,7 @@ def random_scene(api, n_objects=10000, hsize=3840, vsize=2160, seed=0xC0FFEE):
     wall.set_pattern(STRIPE, (0.3, 0.4, 0.8), (0.8, 0.8, 0.9)).set_pattern_transform(api.m_scaling(3.0, 3.0, 3.0))
     wall.set_specular(0.0)
     w.add_object(wall)
-    w.add_light((-30.0, 60.0, -40.0))
+    w.add_light(light)
     cam = _camera(api, hsize, vsize, math.pi / 3.0, (0.0, 12.0, -30.0), (0.0, 8.0, 40.0))
     return w, cam
 
