@@ -551,6 +551,25 @@ template <typename Rec> RT_DEV Rec load_uniform(const Rec *p)
     __builtin_memcpy(&rec, (const RT_CONSTANT_AS Rec *)p, sizeof(Rec));
     return rec;
 }
+// The same, with every word of the record in a scalar register when this returns.  Left to itself the
+// compiler fetches a record's fields one by one where they are first used, behind the branches of the
+// intersection routine: two or three round trips to the scalar cache per object, each waited for, in
+// waves that are little else than such waits.  This way it is one fetch and one wait.
+template <typename Rec> RT_DEV Rec load_uniform_whole(const Rec *p)
+{
+    static_assert(sizeof(Rec) % 4 == 0, "records are whole words");
+    constexpr int kWords = (int)(sizeof(Rec) / 4);
+    uint32_t w[kWords];
+    __builtin_memcpy(w, (const RT_CONSTANT_AS Rec *)p, sizeof(Rec));
+#pragma unroll
+    for (int i = 0; i < kWords; ++i) asm volatile("" : "+s"(w[i]));
+    Rec rec;
+    __builtin_memcpy(&rec, w, sizeof(Rec));
+    return rec;
+}
+#ifndef RTX_WHOLE_RECORD
+#define RTX_WHOLE_RECORD 0
+#endif
 #ifdef RTX_LDS_TABLES
 // Experiment (tools build): the five intersection tables are copied into LDS when a workgroup
 // starts (stage_tables) and the brute-force walk reads its records from there, every lane the
@@ -635,14 +654,26 @@ RT_DEV void walk_table(const Rec *recs, uint32_t n, uint32_t slot0, uint32_t clu
             }
         }
     } else {
+#if RTX_WHOLE_RECORD == 2 && !defined(RTX_LDS_TABLES)
+        if (n == 0u) return;
+        Rec next = load_uniform_whole(recs);
+        for (uint32_t i = 0; i < n; ++i) {
+            const Rec rec = next;
+            if (i + 1u < n) next = load_uniform_whole(recs + i + 1u);
+            body(rec, slot0 + i);
+        }
+#else
         for (uint32_t i = 0; i < n; ++i) {
 #ifdef RTX_LDS_TABLES
             const Rec rec = lds_off != 0xffffffffu ? load_lds<Rec>(lds_off, i) : load_uniform(recs + i);
+#elif RTX_WHOLE_RECORD == 1
+            const Rec rec = load_uniform_whole(recs + i);
 #else
             const Rec rec = load_uniform(recs + i);
 #endif
             body(rec, slot0 + i);
         }
+#endif
     }
 }
 struct KeepAll {

@@ -171,11 +171,20 @@ RT_DEV void primary_ray(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> ro, V
 // tests it takes an 8x8 tile instead (camera_blocks() in rt_launch.h).  There is no loop: the
 // camera block is dead once the ray exists, which leaves the scalar register file to the
 // object tables.  The intersection walk reads the per-frame primary tables.
+// Waves per SIMD the camera kernel is compiled for (the register allocator's ceiling follows from it).
+// Left alone the compiler takes 80-90 vector registers for the f64 variants without bounding-sphere
+// tests (5 waves per SIMD) although 66 do without a spill; their waves are short chains of dependent
+// f64 operations behind two rounds of scalar loads, and more of them side by side is what hides that.
+// The variants with the tests would spill (scratch) and keep the compiler's choice.
+#ifndef RTX_CAM_WAVES
+#define RTX_CAM_WAVES 7u
+#endif
+constexpr uint32_t camera_waves(uint32_t sf) { return (sf & SF_CULL) ? 1u : RTX_CAM_WAVES; }
 #ifndef RTX_CAMERA_ATTR
-#define RTX_CAMERA_ATTR
+#define RTX_CAMERA_ATTR __attribute__((amdgpu_waves_per_eu(camera_waves(SF))))
 #endif
 template <typename R, uint32_t SF, bool OUT8 = false, bool BANDED = false>
-__global__ void __launch_bounds__(kCamBlock) RTX_CAMERA_ATTR
+__global__ void __launch_bounds__(kCamBlock<R>) RTX_CAMERA_ATTR
 k_primary_camera(CameraDev<R> cam, SceneDev<R> S, PrimScene<R> P, uint32_t local0, uint32_t n_rows, uint32_t pieces_per_row,
                  uint32_t remaining, void *__restrict__ fb, QueueDev<R> out_q, StatShard *__restrict__ stats, RowMap map,
                  uint32_t format)
@@ -183,7 +192,7 @@ k_primary_camera(CameraDev<R> cam, SceneDev<R> S, PrimScene<R> P, uint32_t local
 #ifdef RTX_LDS_TABLES
     if constexpr ((SF & SF_CULL) == 0) stage_tables<R>(S);
 #endif
-    const uint32_t piece = __builtin_amdgcn_readfirstlane(blockIdx.x * (kCamBlock / 64) + (threadIdx.x >> 6));
+    const uint32_t piece = __builtin_amdgcn_readfirstlane(blockIdx.x * (kCamBlock<R> / 64) + (threadIdx.x >> 6));
     const uint32_t piece_row = piece / pieces_per_row;
     const uint32_t piece_col = piece - piece_row * pieces_per_row;
     uint32_t row, x;
@@ -349,14 +358,14 @@ hipError_t Launch<R>::primary_camera(uint32_t sf, hipStream_t stream, const Came
                                      const PrimScene<R> &prim, const RowMap &map, uint32_t local0, uint32_t n_rows,
                                      uint32_t remaining, void *fb, uint32_t format, const QueueDev<R> &out_q, StatShard *stats)
 {
-    const uint32_t grid = (uint32_t)camera_blocks(sf, cam.hsize, n_rows);
+    const uint32_t grid = (uint32_t)camera_blocks<R>(sf, cam.hsize, n_rows);
     const uint32_t pieces_per_row = camera_pieces_per_row(sf, cam.hsize);
     // the 8-bit variants exist for the scenes that can use them: those in which nothing reflects or
     // refracts; the variants that deal bands out to parts spare the plain row range their divisions
     const bool banded = map.n_parts != 1u;
     const uint32_t first = banded ? local0 : map.first + local0;  // what the kernel adds its row to
 #define RTX_LAUNCH_CAM(SFV, OUT8, BANDED)                                                                            \
-    hipLaunchKernelGGL((k_primary_camera<R, SFV | SF_PATTERN, OUT8, BANDED>), dim3(grid), dim3(kCamBlock), table_lds_bytes(scene), \
+    hipLaunchKernelGGL((k_primary_camera<R, SFV | SF_PATTERN, OUT8, BANDED>), dim3(grid), dim3(kCamBlock<R>), table_lds_bytes(scene), \
                        stream, cam, scene, prim, first, n_rows, pieces_per_row, remaining, fb, out_q, stats, map, format)
 #define RTX_CALL(SFV)                                                                                                \
     if constexpr (((SFV) & (SF_REFLECTIVE | SF_TRANSPARENT)) == 0) {                                               \

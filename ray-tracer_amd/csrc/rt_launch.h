@@ -34,9 +34,18 @@ template <typename R> constexpr uint32_t bounce_block(uint32_t sf)
 {
     return sizeof(R) == 8 ? ((sf & 16u /* SF_CULL */) ? RTX_RAY_BLOCK_F64 : RTX_BOUNCE_BLOCK_F64_SMALL_SCENE) : RTX_RAY_BLOCK_F32;
 }
-// The camera kernel runs one wave per workgroup: its waves share nothing, and single waves fill
-// the chip's last round more evenly than groups of four (4K headline frame: 61 -> 58.5 us).
-constexpr uint32_t kCamBlock = 64;
+// Threads per workgroup of the camera kernel.  Its waves share nothing.  In f64 one wave per
+// workgroup: single waves fill the chip's last round more evenly than groups of four (4K headline
+// frame: 61 -> 58.5 us).  The chip starts about 4.6 workgroups per nanosecond whatever their size
+// (tools/wave_rate.hip: 28 us for the 129 600 one-wave workgroups of a 4K frame that do nothing, 8 us
+// for 32 400 of four waves), which a frame of short f32 waves runs into.
+#ifndef RTX_CAM_BLOCK_F64
+#define RTX_CAM_BLOCK_F64 64u
+#endif
+#ifndef RTX_CAM_BLOCK_F32
+#define RTX_CAM_BLOCK_F32 64u
+#endif
+template <typename R> constexpr uint32_t kCamBlock = sizeof(R) == 8 ? RTX_CAM_BLOCK_F64 : RTX_CAM_BLOCK_F32;
 
 // Wave-sized pieces of the camera kernel's image for n_rows rows of hsize pixels.  Without
 // bounding-sphere tests a wave takes one 64-pixel row segment (its framebuffer stores are one
@@ -46,11 +55,11 @@ inline uint32_t camera_pieces_per_row(uint32_t sf, uint32_t hsize)
 {
     return (sf & SF_CULL) ? (hsize + 7u) / 8u : (hsize + 63u) / 64u;
 }
-inline uint64_t camera_blocks(uint32_t sf, uint32_t hsize, uint64_t n_rows)
+template <typename R> inline uint64_t camera_blocks(uint32_t sf, uint32_t hsize, uint64_t n_rows)
 {
     const uint64_t piece_rows = (sf & SF_CULL) ? (n_rows + 7u) / 8u : n_rows;
     const uint64_t pieces = (uint64_t)camera_pieces_per_row(sf, hsize) * piece_rows;
-    return (pieces + kCamBlock / 64 - 1) / (kCamBlock / 64);
+    return (pieces + kCamBlock<R> / 64 - 1) / (kCamBlock<R> / 64);
 }
 
 template <typename R>

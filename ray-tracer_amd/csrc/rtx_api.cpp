@@ -749,7 +749,7 @@ template <typename R>
 void size_queues(uint32_t sf, uint32_t levels, uint32_t hsize, uint64_t units, FramePlan *p)
 {
     const uint64_t g = children_per_hit(sf);
-    const uint64_t blocks0 = hsize ? camera_blocks(sf, hsize, units) : (units + kRayBlock<R> - 1) / kRayBlock<R>;
+    const uint64_t blocks0 = hsize ? camera_blocks<R>(sf, hsize, units) : (units + kRayBlock<R> - 1) / kRayBlock<R>;
     uint32_t n_sub = 1;
     while (n_sub < 256 && (uint64_t)n_sub * 2 * 8 <= blocks0) n_sub *= 2;
     p->levels = levels;
@@ -759,7 +759,7 @@ void size_queues(uint32_t sf, uint32_t levels, uint32_t hsize, uint64_t units, F
     for (auto &c : p->cap_sub) c = 0;
     // rays per primary workgroup: kRayBlock of a ray batch, kCamBlock pixels of a frame, of whose
     // 8x8 tiles only `units` rows exist when the chunk is lower than a tile
-    const uint64_t per_block0 = !hsize ? (uint64_t)kRayBlock<R> : ((sf & SF_CULL) && units < 8) ? (kCamBlock / 8) * units : (uint64_t)kCamBlock;
+    const uint64_t per_block0 = !hsize ? (uint64_t)kRayBlock<R> : ((sf & SF_CULL) && units < 8) ? (kCamBlock<R> / 8) * units : (uint64_t)kCamBlock<R>;
     uint64_t cap = ((blocks0 + n_sub - 1) / n_sub) * per_block0 * g;
     for (uint32_t L = 1; L <= levels; ++L) {
         p->cap_sub[L] = cap;
