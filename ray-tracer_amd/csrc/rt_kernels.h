@@ -122,13 +122,13 @@ template <typename R> RT_DEV void store_pixel8(uint8_t *__restrict__ out, uint32
 template <typename R, uint32_t SF, bool CAM, bool OUT8 = false>
 RT_DEV void primary_ray(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> ro, V3<R> rd, uint32_t k, bool valid,
                         uint32_t remaining, void *__restrict__ fb, uint32_t format, const QueueDev<R> &out_q,
-                        StatShard *__restrict__ stats)
+                        StatShard *__restrict__ stats, uint32_t block_id)
 {
     Node<R> nd;
     nd.hit = false;
     nd.has_reflect = nd.has_refract = false;
     nd.lighting = { R(0), R(0), R(0) };
-    const uint32_t sub = blockIdx.x & out_q.sub_mask;
+    const uint32_t sub = block_id & out_q.sub_mask;
     auto children = [&](const Node<R> &c) {
         if constexpr ((SF & (SF_REFLECTIVE | SF_TRANSPARENT)) != 0)
             queue_push2(out_q, sub, c.has_reflect, c.over_point, c.reflectv, c.reflect_factor, c.has_refract, c.under_point,
@@ -162,7 +162,7 @@ RT_DEV void primary_ray(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> ro, V
             store_pixel8<R>(static_cast<uint8_t *>(fb), k, format, nd.lighting.x, nd.lighting.y, nd.lighting.z);
         }
     }
-    count_hits(stats, blockIdx.x, 0, valid && nd.hit);
+    count_hits(stats, block_id, 0, valid && nd.hit);
 }
 
 // Camera rays of local rows [local0, local0 + n_rows) of `map`, one pixel per lane; the output
@@ -185,16 +185,18 @@ constexpr uint32_t camera_waves(uint32_t sf) { return (sf & SF_CULL) ? 1u : RTX_
 #endif
 template <typename R, uint32_t SF, bool OUT8 = false, bool BANDED = false>
 __global__ void __launch_bounds__(kCamBlock<R>) RTX_CAMERA_ATTR
-k_primary_camera(CameraDev<R> cam, SceneDev<R> S, PrimScene<R> P, uint32_t local0, uint32_t n_rows, uint32_t pieces_per_row,
+k_primary_camera(CameraDev<R> cam, SceneDev<R> S, PrimScene<R> P, uint32_t local0, uint32_t n_rows,
                  uint32_t remaining, void *__restrict__ fb, QueueDev<R> out_q, StatShard *__restrict__ stats, RowMap map,
                  uint32_t format)
 {
 #ifdef RTX_LDS_TABLES
     if constexpr ((SF & SF_CULL) == 0) stage_tables<R>(S);
 #endif
-    const uint32_t piece = __builtin_amdgcn_readfirstlane(blockIdx.x * (kCamBlock<R> / 64) + (threadIdx.x >> 6));
-    const uint32_t piece_row = piece / pieces_per_row;
-    const uint32_t piece_col = piece - piece_row * pieces_per_row;
+    // a two-dimensional grid: row of pieces = blockIdx.y (a division by pieces_per_row otherwise, thirty
+    // instructions in front of everything else in waves of three hundred)
+    const uint32_t piece_row = blockIdx.y;
+    const uint32_t piece_col = __builtin_amdgcn_readfirstlane(blockIdx.x * (kCamBlock<R> / 64) + (threadIdx.x >> 6));
+    const uint32_t block_id = blockIdx.y * gridDim.x + blockIdx.x;
     uint32_t row, x;
     if constexpr ((SF & SF_CULL) != 0) {
         row = piece_row * 8u + ((threadIdx.x >> 3) & 7u);
@@ -213,7 +215,7 @@ k_primary_camera(CameraDev<R> cam, SceneDev<R> S, PrimScene<R> P, uint32_t local
             image_row = map.first + ((image_row / map.band) * map.n_parts + map.part) * map.band + image_row % map.band;
         ray_for_pixel(cam, x, image_row, ro, rd);
     }
-    primary_ray<R, SF, true, OUT8>(S, P, ro, rd, row * cam.hsize + x, valid, remaining, fb, format, out_q, stats);
+    primary_ray<R, SF, true, OUT8>(S, P, ro, rd, row * cam.hsize + x, valid, remaining, fb, format, out_q, stats, block_id);
     RTX_PHASE_FLUSH();
 }
 
@@ -235,7 +237,7 @@ k_primary_rays(SceneDev<R> S, const double *__restrict__ rays, uint32_t n, uint3
         ro = { R(r[0]), R(r[1]), R(r[2]) };
         rd = { R(r[3]), R(r[4]), R(r[5]) };
     }
-    primary_ray<R, SF, false>(S, none, ro, rd, k, valid, remaining, fb, 0u, out_q, stats);
+    primary_ray<R, SF, false>(S, none, ro, rd, k, valid, remaining, fb, 0u, out_q, stats, blockIdx.x);
 }
 
 // First kernel of a frame: zero the queue counters and the hit counters, and let one thread
@@ -358,15 +360,15 @@ hipError_t Launch<R>::primary_camera(uint32_t sf, hipStream_t stream, const Came
                                      const PrimScene<R> &prim, const RowMap &map, uint32_t local0, uint32_t n_rows,
                                      uint32_t remaining, void *fb, uint32_t format, const QueueDev<R> &out_q, StatShard *stats)
 {
-    const uint32_t grid = (uint32_t)camera_blocks<R>(sf, cam.hsize, n_rows);
-    const uint32_t pieces_per_row = camera_pieces_per_row(sf, cam.hsize);
+    const dim3 grid(camera_blocks_per_row<R>(sf, cam.hsize), camera_piece_rows(sf, n_rows));
+    if (grid.y > 65535u) return hipErrorInvalidValue;  // plan_frame keeps chunks below that
     // the 8-bit variants exist for the scenes that can use them: those in which nothing reflects or
     // refracts; the variants that deal bands out to parts spare the plain row range their divisions
     const bool banded = map.n_parts != 1u;
     const uint32_t first = banded ? local0 : map.first + local0;  // what the kernel adds its row to
 #define RTX_LAUNCH_CAM(SFV, OUT8, BANDED)                                                                            \
-    hipLaunchKernelGGL((k_primary_camera<R, SFV | SF_PATTERN, OUT8, BANDED>), dim3(grid), dim3(kCamBlock<R>), table_lds_bytes(scene), \
-                       stream, cam, scene, prim, first, n_rows, pieces_per_row, remaining, fb, out_q, stats, map, format)
+    hipLaunchKernelGGL((k_primary_camera<R, SFV | SF_PATTERN, OUT8, BANDED>), grid, dim3(kCamBlock<R>), table_lds_bytes(scene), \
+                       stream, cam, scene, prim, first, n_rows, remaining, fb, out_q, stats, map, format)
 #define RTX_CALL(SFV)                                                                                                \
     if constexpr (((SFV) & (SF_REFLECTIVE | SF_TRANSPARENT)) == 0) {                                               \
         if (format != 0u) { if (banded) RTX_LAUNCH_CAM(SFV, true, true); else RTX_LAUNCH_CAM(SFV, true, false); }    \

@@ -55,11 +55,17 @@ inline uint32_t camera_pieces_per_row(uint32_t sf, uint32_t hsize)
 {
     return (sf & SF_CULL) ? (hsize + 7u) / 8u : (hsize + 63u) / 64u;
 }
+// The camera launch is a two-dimensional grid: blockIdx.y = row of pieces (at most 65 535 of them),
+// blockIdx.x = workgroup within the row.
+inline uint64_t camera_piece_rows(uint32_t sf, uint64_t n_rows) { return (sf & SF_CULL) ? (n_rows + 7u) / 8u : n_rows; }
+template <typename R> inline uint32_t camera_blocks_per_row(uint32_t sf, uint32_t hsize)
+{
+    return (camera_pieces_per_row(sf, hsize) + kCamBlock<R> / 64 - 1) / (kCamBlock<R> / 64);
+}
+constexpr uint64_t kCameraMaxRows = 65535u;  // rows of one camera launch (of 8x8 tiles even more would do)
 template <typename R> inline uint64_t camera_blocks(uint32_t sf, uint32_t hsize, uint64_t n_rows)
 {
-    const uint64_t piece_rows = (sf & SF_CULL) ? (n_rows + 7u) / 8u : n_rows;
-    const uint64_t pieces = (uint64_t)camera_pieces_per_row(sf, hsize) * piece_rows;
-    return (pieces + kCamBlock<R> / 64 - 1) / (kCamBlock<R> / 64);
+    return (uint64_t)camera_blocks_per_row<R>(sf, hsize) * camera_piece_rows(sf, n_rows);
 }
 
 template <typename R>

@@ -779,7 +779,8 @@ int plan_frame(size_t limit, uint32_t sf, uint32_t max_depth, uint32_t hsize, ui
     const bool secondary = children_per_hit(sf) != 0 && max_depth > 0;
     const uint32_t levels = secondary ? max_depth : 0;
     // one launch covers at most 2^31 - 256 primary rays
-    const uint64_t max_units = hsize ? std::max<uint64_t>(1, 0x7fffff00ull / hsize) : 0x7fffff00ull;
+    // (and, of a frame, at most the rows a camera launch can number)
+    const uint64_t max_units = hsize ? std::min<uint64_t>(std::max<uint64_t>(1, 0x7fffff00ull / hsize), kCameraMaxRows) : 0x7fffff00ull;
     auto fits = [&](uint64_t units) {
         size_queues<R>(sf, levels, hsize, units, p);
         if (p->bytes > limit) return false;
