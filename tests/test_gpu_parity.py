@@ -311,6 +311,37 @@ def test_tiled_camera_rays_in_chunks_lower_than_a_tile(orc, rta):
         assert np.abs(out - frames[0][0]).max() <= 1e-12
 
 
+@pytest.mark.parametrize("name,culled", [("glass", False), ("random", True)])
+def test_frames_taller_than_one_camera_launch(orc, rta, name, culled):
+    """A camera launch numbers its rows of pieces with blockIdx.y, 65 535 of them at most: a frame
+    with more rows is rendered in chunks, and comes out as the same rows rendered in ranges of
+    their own and as the oracle renders them."""
+    from ray_tracer_amd import scenes
+    H, W = 70001, 4
+    kw = dict(hsize=W, vsize=H)
+    if name == "random":
+        kw.update(n_objects=150, seed=5)
+    gw, gcam = scenes.SCENES[name](rta.api, **kw)
+    ow, ocam = scenes.SCENES[name](orc.api, **kw)
+    ctx = rta.Context()
+    if culled:
+        ctx.set_cull_threshold(0)
+    scene = rta.Scene(ctx, rta.flatten(gw))
+    assert bool(scene.features()["bounding_sphere_tests"]) == culled
+    cd = rta.camera_desc(gcam)
+    out = np.empty((H, W, 3))
+    st = rta.Stats()
+    rta._check(rta.rtx_render(ctx.h, scene.h, cd, 5, rta.F64, 0, H, out.ctypes.data, out.nbytes, None, None, st))
+    assert st.n_chunks >= 2
+    for a, b in [(0, 9), (34990, 35013), (65530, 65541), (H - 7, H)]:
+        part = np.empty((b - a, W, 3))
+        rta._check(rta.rtx_render(ctx.h, scene.h, cd, 5, rta.F64, a, b, part.ctypes.data, part.nbytes, None, None, None))
+        assert np.abs(part - out[a:b]).max() <= 1e-12
+        assert np.abs(orc.render_rows(ocam, ow, row_begin=a, row_end=b) - out[a:b]).max() <= TOL
+    scene.close()
+    ctx.close()
+
+
 def test_bounding_sphere_tests_change_nothing(orc, rta):
     """Ray counters and colours do not depend on whether objects are skipped by their bounding
     spheres (threshold 0 = always test, 2^32-1 = never).  Colours are compared to 1e-12: the
