@@ -84,6 +84,9 @@ static __device__ double g_slow_rays[64 * 8];
 #endif
 // COLD_LDS: the launch comes with cold_lds_bytes() of dynamic LDS and the scene has at most
 // kColdLdsObjects objects (launch_bounce sees to both).
+#ifndef RTX_WIDE_RAYS  // a level of at most this many rays gets one ray per wave (scenes with the sphere hierarchy)
+#define RTX_WIDE_RAYS 65536u
+#endif
 #ifndef RTX_BOUNCE_ATTR  // occupancy experiments, e.g. -DRTX_BOUNCE_ATTR='__attribute__((amdgpu_waves_per_eu(5,5)))'
 #define RTX_BOUNCE_ATTR
 #endif
@@ -106,7 +109,7 @@ k_bounce(BounceArgs<R> args_in_kernarg_segment)
     // one ray per wave for short levels: scenes with the sphere hierarchy whose rays carry no container
     // bookkeeping (that is kept per lane and not joined across lanes)
     constexpr bool kWide = (SF & SF_CULL) != 0 && (SF & SF_TRANSPARENT) == 0 && !kLaneWalk;
-    constexpr uint32_t kWideRays = 65536u;
+    constexpr uint32_t kWideRays = RTX_WIDE_RAYS;
 #ifdef RTX_LDS_TABLES
     if constexpr ((SF & SF_CULL) == 0) stage_tables<R>(args_in_kernarg_segment.S);
 #endif
