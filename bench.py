@@ -64,11 +64,13 @@ def parse_args():
     return ap.parse_args()
 
 
-def build_scene(rta, name, width, height, objects):
+def build_scene(rta, name, width, height, objects, n_lights=1):
     from ray_tracer_amd import scenes
     kw = dict(hsize=width, vsize=height)
     if name == "random":
         kw["n_objects"] = objects
+    if n_lights != 1:
+        kw["n_lights"] = n_lights
     return scenes.SCENES[name](rta.api, **kw)
 
 
@@ -446,29 +448,33 @@ def moved_camera_desc(rta, cam):
 def extra_scenes(rta, ctx, args):
     """The other single-GPU configurations, a few frames each (not the headline)."""
     res = {}
+    # (the last one is the frame the multi-GPU configuration shards, here on one GPU: the reference shades with
+    # lights[0] only, so its four lights cost what one does)
     cases = [("default", "f32", {}), ("spheres_on_plane", "f64", {}), ("glass", "f64", {}), ("glass", "f32", {}),
-             ("random", "f64", {"objects": 10000}), ("random", "f32", {"objects": 10000})]
+             ("random", "f64", {"objects": 10000}), ("random", "f32", {"objects": 10000}),
+             ("glass", "f64", {"width": 7680, "height": 4320, "n_lights": 4, "key": "glass_4lights_7680x4320_f64"})]
     never = (1 << 64) - 1
 
     def frame_time(name, precision, kw, measured_above=None):
         prec = rta.F64 if precision == "f64" else rta.F32
         tdtype = torch.float64 if prec == rta.F64 else torch.float32
-        world, cam = build_scene(rta, name, args.width, args.height, kw.get("objects", args.objects))
+        width, height = kw.get("width", args.width), kw.get("height", args.height)
+        world, cam = build_scene(rta, name, width, height, kw.get("objects", args.objects), kw.get("n_lights", 1))
         flat = rta.flatten(world)
         own = rta.Context(torch.cuda.current_device())  # a context of its own: what it holds afterwards is this scene's
         if measured_above is not None:
             own.set_measured_queues(measured_above)
         scene = rta.Scene(own, flat)
         cd = rta.camera_desc(cam)
-        tile = torch.empty((args.height, args.width, 3), dtype=tdtype, device="cuda")
+        tile = torch.empty((height, width, 3), dtype=tdtype, device="cuda")
         nbytes = tile.numel() * tile.element_size()
         st = {}
-        rta.render_device(own, scene, cd, args.depth, prec, 0, args.height, tile.data_ptr(), nbytes, None, st)
+        rta.render_device(own, scene, cd, args.depth, prec, 0, height, tile.data_ptr(), nbytes, None, st)
         frames = 3 if st["kernel_ms"] > 50 else 20
         times, primary = [], []
         for _ in range(frames):
             s2 = {}
-            rta.render_device(own, scene, cd, args.depth, prec, 0, args.height, tile.data_ptr(), nbytes, None, s2)
+            rta.render_device(own, scene, cd, args.depth, prec, 0, height, tile.data_ptr(), nbytes, None, s2)
             times.append(s2["kernel_ms"])
             primary.append(s2["primary_kernel_ms"])
         culled = bool(scene.features()["bounding_sphere_tests"])
@@ -482,7 +488,9 @@ def extra_scenes(rta, ctx, args):
         ms, st, flat, culled, queue_gb = frame_time(name, precision, kw)
         prec = rta.F64 if precision == "f64" else rta.F32
         rays = st["color_rays"] + st["shadow_rays"]
-        flops = algorithmic_flops(flat["shape_type"], args.height * args.width, st["color_rays"], st["shadow_rays"])
+        flops = algorithmic_flops(flat["shape_type"], kw.get("height", args.height) * kw.get("width", args.width), st["color_rays"],
+                                  st["shadow_rays"])
+        key = kw.get("key", "%s_%s" % (name, precision))
         peak = FP64_VECTOR_PEAK_TFLOPS if prec == rta.F64 else FP32_VECTOR_PEAK_TFLOPS
         # A call that reports counters clears them and refills the per-camera tables first (k_frame_begin, which
         # the headline's timed loop skips while the camera stands still): frame_ms is from the start of that
@@ -490,7 +498,7 @@ def extra_scenes(rta, ctx, args):
         # this one launch the roofline fraction is taken over it, as the headline's is.
         k_ms = st["median_primary_kernel_ms"]
         roof_ms = k_ms if st["n_launches"] == 1 else ms
-        res["%s_%s" % (name, precision)] = {
+        res[key] = {
             "frame_ms": ms, "camera_kernel_ms": k_ms,
             "Mrays_per_s": rays / (ms * 1e-3) / 1e6, "rays": rays, "objects": int(len(flat["shape_type"])),
             "rays_per_level": st["rays_per_level"], "launches": st["n_launches"], "chunks": st["n_chunks"],
@@ -503,7 +511,7 @@ def extra_scenes(rta, ctx, args):
             # device memory the secondary-ray queues of this frame hold
             "queue_GB": queue_gb,
         }
-        if name == "glass":
+        if name == "glass" and "key" not in kw:
             # the library's default for a frame this size is to size each level's queue from the lengths of
             # the level before (a host round trip per level); the same frame with every queue sized for the
             # worst case on the host, which is what a caller who passes a stream of its own gets
