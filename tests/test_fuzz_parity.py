@@ -4,6 +4,7 @@ transformation list (with shears) or as matrices, value-identical twins, and opt
 groups; cameras are random too.  Frames must agree to 1e-9 with equal ray counters, and the
 per-ray intermediate results must be bit-identical."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -83,7 +84,7 @@ def build_world(api, seed, groups, res_scale=1):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RTX_FUZZ_SEEDS", "48"))))  # more seeds for a one-off soak
 def test_random_worlds_match_the_oracle(orc, rta, seed):
     import test_gpu_parity as tg
     groups = seed % 2 == 1
