@@ -175,11 +175,15 @@ RT_DEV void primary_ray(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> ro, V
 // Left alone the compiler takes 80-90 vector registers for the f64 variants without bounding-sphere
 // tests (5 waves per SIMD) although 66 do without a spill; their waves are short chains of dependent
 // f64 operations behind two rounds of scalar loads, and more of them side by side is what hides that.
-// The variants with the tests would spill (scratch) and keep the compiler's choice.
+// The variants with the tests spill at 6 waves (40-130 bytes of scratch; camera launch of a 10 002-object
+// frame 1.05 -> 1.16 ms) and keep the compiler's choice.
 #ifndef RTX_CAM_WAVES
 #define RTX_CAM_WAVES 7u
 #endif
-constexpr uint32_t camera_waves(uint32_t sf) { return (sf & SF_CULL) ? 1u : RTX_CAM_WAVES; }
+#ifndef RTX_CAM_WAVES_CULL
+#define RTX_CAM_WAVES_CULL 1u
+#endif
+constexpr uint32_t camera_waves(uint32_t sf) { return (sf & SF_CULL) ? RTX_CAM_WAVES_CULL : RTX_CAM_WAVES; }
 #ifndef RTX_CAMERA_ATTR
 #define RTX_CAMERA_ATTR __attribute__((amdgpu_waves_per_eu(camera_waves(SF))))
 #endif
