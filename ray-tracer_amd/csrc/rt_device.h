@@ -785,7 +785,8 @@ struct PrimSphereCull {
     RT_DEV bool group(uint32_t g) const { return !dead & may_hit_primary<R, LINE>(head(grp + g), u, reach()); }
 };
 
-// Experiment (tools build, -DRTX_LANE_WALK; measured slower, see tools/README.md):
+// Experiment (tools build, -DRTX_LANE_WALK; measured slower: the five bounce levels of a 4K frame of 10 002
+// objects took 3.1 / 2.3 / 1.05 / 0.67 / 0.38 ms against 1.28 / 0.71 / 0.41 / 0.19 / 0.13 with the walk per wave):
 // the same three-level walk with every lane on its own: for rays that have nothing to do with
 // each other (reflected and refracted rays, and the shadow rays of their hits) the wave-uniform
 // walk above visits the union of what 64 rays need, which is most of the scene, one dependent
