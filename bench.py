@@ -4,12 +4,17 @@
   python bench.py [--gpus N] [--steps K] [--warmup W] [--scene default] [--precision f64]
 
 One step = one frame: every pixel's World::color_at at recursion depth 5, scene already
-resident in HBM, framebuffer left in HBM (rank 0's HBM after the gather when N > 1).  The
-headline workload is the reference's default world at 3840x2160 in f64.  With N > 1 (launched
-by torch.distributed.run, one rank per GPU) the frame is split into row tiles, each rank
-renders the 10-row bands that fall to it (band b goes to rank b mod N, so every rank gets its
-share of cheap and of dear rows) and one RCCL gather assembles the frame on rank 0; the step
-time is the maximum over ranks.  Rank 0 prints one JSON line.
+resident in HBM, framebuffer left in HBM (the first GPU's HBM when N > 1).  The headline
+workload is the glass / mirror scene (reflection + refraction, Fresnel) at 3840x2160 in f64; the
+other configurations are reported under "extra".  With N > 1 the frame is split into 10-row
+bands, band b goes to GPU b mod N (every GPU gets its share of cheap and of dear rows), nothing
+travels while the GPUs render and the bands are then assembled on the first GPU:
+  * launched by torch.distributed.run (WORLD_SIZE set, one rank per GPU): one RCCL gather; the
+    step time is the maximum over ranks; --gpus must equal WORLD_SIZE;
+  * launched as a plain process with --gpus N: the N GPUs are driven from this one process
+    through rtx_multi_* (one stream per GPU, strided peer copies into the first GPU).
+Fewer than N visible GPUs is an error (RTX_BENCH_SAME_DEVICE=1 names GPU 0 N times instead: a
+rehearsal of the code path on a one-GPU box, not a measurement).  Rank 0 prints one JSON line.
 """
 import argparse
 import json
@@ -41,11 +46,9 @@ FP32_VECTOR_PEAK_TFLOPS = 157.3  # packed FP32 vector peak
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # a frame of the headline scene takes ~70 us: 2000 of them amortise the ~2 ms the GPU needs to
-    # come out of idle after the fence that precedes the timed region
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--scene", default="default", choices=["default", "spheres_on_plane", "glass", "random"])
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--scene", default="glass", choices=["default", "spheres_on_plane", "glass", "random"])
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--depth", type=int, default=5)
@@ -144,7 +147,7 @@ def measured_traffic(scene_name, precision, width, height, kernel_prefix):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of
     this workload (profiles/), or None when there is no such profile.  FETCH_SIZE and WRITE_SIZE
     count KiB; FETCH_SIZE is doubled as gfx950 tallies 128-byte read requests at 64 bytes."""
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_%s_%dx%d_%s_pmc.json" % (rnd, scene_name, width, height, precision))
         if not os.path.exists(path):
             continue
@@ -156,17 +159,53 @@ def measured_traffic(scene_name, precision, width, height, kernel_prefix):
     return None, None
 
 
+def launch_mode(args, environ):
+    """How the N GPUs of --gpus are driven: ("single", 1), ("ranks", N) under torch.distributed.run
+    (one rank per GPU; WORLD_SIZE must agree with --gpus), or ("multi", N) from this one process."""
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be at least 1")
+    if "WORLD_SIZE" in environ:
+        world = int(environ["WORLD_SIZE"])
+        if world != args.gpus:
+            raise SystemExit("bench.py: --gpus %d does not match WORLD_SIZE=%d of the launcher; the line would report the wrong "
+                             "number of GPUs" % (args.gpus, world))
+        return ("ranks", world) if world > 1 or environ.get("RTX_BENCH_DIST") == "1" else ("single", 1)
+    if environ.get("RTX_BENCH_DIST") == "1" and args.gpus == 1:
+        return ("ranks", 1)  # rehearsal of the multi-rank code path with one rank
+    return ("multi", args.gpus) if args.gpus > 1 else ("single", 1)
+
+
+def device_ids_for(n, visible, environ):
+    """GPU ids of an N-GPU run in one process: 0..N-1, all of which must exist."""
+    if visible >= n:
+        return list(range(n))
+    if environ.get("RTX_BENCH_SAME_DEVICE") == "1" and visible >= 1:
+        return [0] * n  # rehearsal: the same GPU named n times
+    raise SystemExit("bench.py: --gpus %d but only %d GPU(s) are visible; refusing to report a %d-GPU number from fewer GPUs"
+                     % (n, visible, n))
+
+
+def bounce_flops(shape_types, n_pixels, st, primary_hits):
+    """Algorithmic flops of the recursion levels below the primary rays of one frame."""
+    per_ray = float(sum(F_TEST[int(t)] for t in shape_types))
+    color = st["color_rays"] - n_pixels
+    shadow = st["shadow_rays"] - primary_hits
+    return per_ray * (color + shadow) + F_SHADE * shadow
+
+
 def main():
     args = parse_args()
-    world_size = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    mode, world_size = launch_mode(args, os.environ)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render loop has no CPU path")
+    if mode == "multi":
+        return main_multi(args)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     # RTX_BENCH_DIST=1 takes the multi-rank code path (process group, gather, reductions) with a
     # single rank too: a rehearsal of that path on a one-GPU box, not a measurement
-    distributed = world_size > 1 or os.environ.get("RTX_BENCH_DIST") == "1"
+    distributed = mode == "ranks"
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:  # the single-rank rehearsal: any free port
@@ -198,6 +237,11 @@ def main():
     world, cam = build_scene(rta, args.scene, args.width, args.height, args.objects)
     flat = rta.flatten(world)
     ctx = rta.Context(local_rank)
+    # The timed steps pass a stream, and such calls size their ray queues for the worst case on the host
+    # (they cannot wait for a level's lengths); the calls below that read counters and kernel times
+    # return finished frames and would size them level by level instead.  One sizing for both, so that
+    # the kernel times are those of the kernels the timed region ran.
+    ctx.set_measured_queues((1 << 64) - 1)
     scene = rta.Scene(ctx, flat)
     cd = rta.camera_desc(cam)
     W, H = args.width, args.height
@@ -214,8 +258,8 @@ def main():
     assert stream != 0
     frame = torch.empty((H, W) + tuple(part.shape[2:]), dtype=part.dtype, device="cuda") if distributed and rank == 0 else None
 
-    def render(stats=None, desc=cd):
-        rta.render_part_device(ctx, scene, desc, args.depth, prec, sharding.BAND_SIZE, world_size, rank, fmt, part.data_ptr(),
+    def render(stats=None, desc=cd, depth=args.depth):
+        rta.render_part_device(ctx, scene, desc, depth, prec, sharding.BAND_SIZE, world_size, rank, fmt, part.data_ptr(),
                                part_bytes, stream, stats)
 
     def step():
@@ -230,12 +274,15 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # ray counts of this rank's part (deterministic per scene) and per-kernel device time
-    st = {}
+    # ray counts of this rank's part (deterministic per scene) and per-kernel device time; the primary
+    # rays' own hits (a frame of depth 0 shades the same hits and casts nothing further)
+    st, st0 = {}, {}
     render(st)
+    render(st0, depth=0)
+    primary_hits = st0["shadow_rays"]
     t_ramp = time.perf_counter()
     while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
-        for _ in range(20):
+        for _ in range(5):
             render()
         torch.cuda.synchronize()
     for _ in range(args.warmup):
@@ -281,13 +328,14 @@ def main():
         fence()
         rgba8_step_wall = time.perf_counter() - t8
 
-    # average device time of the dominant kernel (HIP events around it on its own stream)
-    k_primary, k_all = [], []
+    # average device time of the kernels (HIP events around them on their own stream)
+    k_primary, k_all, k_levels = [], [], []
     for _ in range(min(args.steps, 50)):
         s2 = {}
         render(s2)
         k_primary.append(s2["primary_kernel_ms"])
         k_all.append(s2["kernel_ms"])
+        k_levels.append(s2["levels_ms"])
 
     single = not distributed
     moving_ms = host_ms = host_rgba8_ms = rgba8_ms = None
@@ -351,11 +399,21 @@ def main():
         fb_bytes = n_pix_part * (4 if fmt else 3 * elem)
         flops_part = algorithmic_flops(flat["shape_type"], n_pix_part, st["color_rays"], st["shadow_rays"])
         single_kernel = st["n_launches"] == 1
-        k_ms = float(np.mean(k_primary)) if single_kernel else float(np.mean(k_all))
         peak = FP64_VECTOR_PEAK_TFLOPS if prec == rta.F64 else FP32_VECTOR_PEAK_TFLOPS
-        achieved = flops_part / (k_ms * 1e-3) / 1e12
-        traffic, traffic_source = (measured_traffic(args.scene, args.precision, W, H, "k_primary_camera")
-                                   if single_kernel and n_gpus == 1 else (None, None))
+        culled = bool(scene.features()["bounding_sphere_tests"])
+        if single_kernel:
+            # the frame is one launch of the camera kernel
+            roof_kernel, launches = "k_primary_camera", 1
+            k_ms = float(np.mean(k_primary))
+            flops_launch = flops_part
+        else:
+            # the dominant kernel is k_bounce, one launch per recursion level: its own algorithmic flops
+            # (everything below the primary rays) over its own time, per launch
+            roof_kernel, launches = "k_bounce", st["n_launches"] - 1
+            k_ms = float(np.mean(k_levels)) / launches
+            flops_launch = bounce_flops(flat["shape_type"], n_pix_part, st, primary_hits) / launches
+        achieved = flops_launch / (k_ms * 1e-3) / 1e12
+        traffic, traffic_source = (measured_traffic(args.scene, args.precision, W, H, roof_kernel) if n_gpus == 1 else (None, None))
         out = {
             "metric": "Mrays/s (primary+secondary) at 4K depth-5; frame ms at 1/2/4/8 GPUs",
             "value": value,
@@ -375,12 +433,14 @@ def main():
                 "rays_per_frame": rays,
                 "color_rays": color_rays,
                 "shadow_rays": shadow_rays,
+                "rays_per_level": st["rays_per_level"] if n_gpus == 1 else None,
                 "parallelism": ("10-row bands dealt out to %d ranks + 1 gather of %s" % (n_gpus, "RGBA8 pixels" if fmt else "values"))
                 if distributed else "single GPU",
             },
             "roofline": {
                 "bound": "valu",
-                "kernel": "k_primary_camera" if single_kernel else "k_primary_camera + k_bounce (all levels)",
+                "kernel": roof_kernel,
+                "launches_per_frame": launches,
                 "achieved": achieved,
                 "peak": peak,
                 "unit": "TFLOP/s",
@@ -389,20 +449,27 @@ def main():
                 "traffic": traffic,
                 "traffic_source": traffic_source,
                 "kernel_ms": k_ms,
-                "algorithmic_flops_per_launch": flops_part,
-                "bounding_sphere_tests": scene.features()["bounding_sphere_tests"],
+                "algorithmic_flops_per_launch": flops_launch,
+                "bounding_sphere_tests": culled,
                 # with bounding-sphere tests most of the algorithm's ray/object tests are never executed:
                 # "achieved" then counts work that was skipped and "frac" says nothing about the ALUs
-                "frac_is_meaningful": not scene.features()["bounding_sphere_tests"],
-                # the same launch against the other roof: framebuffer bytes (the only HBM traffic) over the HBM peak
-                "hbm": {"achieved": fb_bytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": fb_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+                "frac_is_meaningful": not culled,
+                # the whole frame (every launch) against the same roof
+                "whole_frame": {"kernel_ms": float(np.mean(k_all)), "algorithmic_flops": flops_part,
+                                "frac": flops_part / (float(np.mean(k_all)) * 1e-3) / 1e12 / peak},
+                # the frame against the other roof: framebuffer bytes (the only traffic the algorithm needs) over the HBM peak
+                "hbm": {"achieved": fb_bytes / (float(np.mean(k_all)) * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": fb_bytes / (float(np.mean(k_all)) * 1e-3) / 1e9 / HBM_PEAK_GBPS},
             },
             "frame": {
                 "clock_ramp_ms_before_warmup": args.ramp_ms,
                 "device_ms_per_frame": dev_ms,
+                "camera_kernel_ms": float(np.mean(k_primary)),
+                "levels_ms": float(np.mean(k_levels)),
                 "color_only_Mrays_per_s": color_rays / (ms_per_step * 1e-3) / 1e6,
                 "launches_per_frame": st["n_launches"],
+                "queue_GB": ctx.queue_bytes() / 1e9,
+                "queue_sizing": "worst case, on the host (calls on a caller's stream)",
             },
         }
         if single:
@@ -428,13 +495,107 @@ def main():
                 out["frame"]["rgba8_gather_bytes"] = (H - sharding.part_rows(H, world_size, 0)) * W * 4
         if not args.no_cpu_baseline and n_gpus == 1:
             out["cpu_baseline"] = cpu_baseline(args.scene, W, H, args.depth, args.objects, args.cpu_seconds)
-        if not args.no_extra and single and args.scene == "default" and args.precision == "f64":
+            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        if not args.no_extra and single and args.scene == "glass" and args.precision == "f64":
             out["extra"] = extra_scenes(rta, ctx, args)
         print(json.dumps(out))
     scene.close()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main_multi(args):
+    """--gpus N from one process: the frame on N GPUs through rtx_multi_* (what a single-process
+    caller such as the reference's binary would use), assembled in the first GPU's memory."""
+    n = args.gpus
+    ids = device_ids_for(n, torch.cuda.device_count(), os.environ)
+    rta = entry.load_package()
+    prec = rta.F64 if args.precision == "f64" else rta.F32
+    tdtype = torch.float64 if prec == rta.F64 else torch.float32
+    world, cam = build_scene(rta, args.scene, args.width, args.height, args.objects)
+    flat = rta.flatten(world)
+    W, H = args.width, args.height
+    fmt = rta.PIXELS_RGBA8 if args.gather == "rgba8" else 0
+    torch.cuda.set_device(ids[0])
+    frame = (torch.empty((H, W, 4), dtype=torch.uint8, device="cuda") if fmt else torch.empty((H, W, 3), dtype=tdtype, device="cuda"))
+    nbytes = frame.numel() * frame.element_size()
+    multi = rta.Multi(ids)
+    scene_h = multi.upload(flat)
+    cd = rta.camera_desc(cam)
+
+    def step(stats=None, flags=0):
+        multi.render(scene_h, cd, args.depth, prec, fmt, frame.data_ptr(), nbytes, on_device=True, flags=flags, stats=stats)
+
+    counted = {}
+    step(counted, rta.MULTI_COUNT_RAYS)
+    t_ramp = time.perf_counter()
+    while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
+        step()
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()  # returns when every GPU's bands are in the frame
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    render_ms, gather_ms = [], []
+    for _ in range(min(args.steps, 20)):
+        s2 = {}
+        step(s2)
+        render_ms.append(s2["render_ms"])
+        gather_ms.append(s2["gather_ms"])
+    ms_per_step = wall * 1e3 / args.steps
+    rays = counted["color_rays"] + counted["shadow_rays"]
+    flops = algorithmic_flops(flat["shape_type"], W * H, counted["color_rays"], counted["shadow_rays"])
+    peak = (FP64_VECTOR_PEAK_TFLOPS if prec == rta.F64 else FP32_VECTOR_PEAK_TFLOPS) * n
+    r_ms = float(np.mean(render_ms))
+    out = {
+        "metric": "Mrays/s (primary+secondary) at 4K depth-5; frame ms at 1/2/4/8 GPUs",
+        "value": rays / (ms_per_step * 1e-3) / 1e6,
+        "unit": "Mrays/s",
+        "n_gpus": n,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": args.precision,
+        "data": "synthetic",
+        "config": {
+            "workload": "%s scene %dx%d depth %d, %s" % (args.scene, W, H, args.depth, args.precision),
+            "objects": int(len(flat["shape_type"])),
+            "rays_per_frame": rays,
+            "color_rays": counted["color_rays"],
+            "shadow_rays": counted["shadow_rays"],
+            "parallelism": "one process: 10-row bands dealt out to %d GPUs (rtx_multi), strided peer copies of %s into GPU %d"
+                           % (n, "RGBA8 pixels" if fmt else "values", ids[0]),
+            "device_ids": ids,
+            "rehearsal_same_device": len(set(ids)) != len(ids),
+        },
+        "roofline": {
+            "bound": "valu",
+            "kernel": "k_primary_camera + k_bounce on every GPU (slowest GPU's part)",
+            "achieved": flops / (r_ms * 1e-3) / 1e12,
+            "peak": peak,
+            "unit": "TFLOP/s",
+            "frac": flops / (r_ms * 1e-3) / 1e12 / peak,
+            "traffic": None,
+            "kernel_ms": r_ms,
+            "algorithmic_flops_per_launch": flops,
+        },
+        "frame": {
+            "render_only_ms": r_ms,
+            "gather_ms": float(np.mean(gather_ms)),
+            "gather_bytes": int(s2["gather_bytes"]),
+            "gather_format": "rgba8" if fmt else args.precision,
+            "render_only_Mrays_per_s": rays / (r_ms * 1e-3) / 1e6,
+        },
+    }
+    print(json.dumps(out))
+    multi.close()
 
 
 def moved_camera_desc(rta, cam):
@@ -450,7 +611,7 @@ def extra_scenes(rta, ctx, args):
     res = {}
     # (the last one is the frame the multi-GPU configuration shards, here on one GPU: the reference shades with
     # lights[0] only, so its four lights cost what one does)
-    cases = [("default", "f32", {}), ("spheres_on_plane", "f64", {}), ("glass", "f64", {}), ("glass", "f32", {}),
+    cases = [("default", "f64", {}), ("default", "f32", {}), ("spheres_on_plane", "f64", {}), ("glass", "f64", {}), ("glass", "f32", {}),
              ("random", "f64", {"objects": 10000}), ("random", "f32", {"objects": 10000}),
              ("glass", "f64", {"width": 7680, "height": 4320, "n_lights": 4, "key": "glass_4lights_7680x4320_f64"})]
     never = (1 << 64) - 1
@@ -520,7 +681,7 @@ def extra_scenes(rta, ctx, args):
                                                                       "Mrays_per_s": rays / (ms_w * 1e-3) / 1e6}
     if not args.no_cpu_baseline:
         # the oracle beside the other two scenes as well (short samples: a few seconds of CPU work each)
-        for name in ("glass", "random"):
+        for name in ("default", "random"):
             base = cpu_baseline(name, args.width, args.height, args.depth, 10000, min(args.cpu_seconds, 6.0))
             res["%s_f64" % name]["cpu_baseline"] = base
             res["%s_f64" % name]["gpu_over_cpu"] = res["%s_f64" % name]["Mrays_per_s"] / base["value"]

@@ -116,6 +116,8 @@ typedef struct rtx_stats {
     double total_ms;          /* host wall time of the call, copies included */
     uint32_t n_launches;      /* kernels launched */
     uint32_t n_chunks;        /* row chunks the frame was split into to bound queue memory */
+    double levels_ms;         /* device time from the end of the first chunk's primary-ray kernel to the end of the
+                                 frame's kernels: for a frame of one chunk, its recursion levels (one launch each) */
 } rtx_stats;
 
 /* Invoked from the calling thread after each finished row chunk with the number of pixels

@@ -57,13 +57,13 @@ class Stats(C.Structure):
     """rtx_stats"""
     _fields_ = [("color_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("rays_per_level", C.c_uint64 * 8),
                 ("kernel_ms", C.c_double), ("primary_kernel_ms", C.c_double), ("total_ms", C.c_double),
-                ("n_launches", C.c_uint32), ("n_chunks", C.c_uint32)]
+                ("n_launches", C.c_uint32), ("n_chunks", C.c_uint32), ("levels_ms", C.c_double)]
 
     def as_dict(self):
         return dict(color_rays=self.color_rays, shadow_rays=self.shadow_rays,
                     rays_per_level=list(self.rays_per_level), kernel_ms=self.kernel_ms,
                     primary_kernel_ms=self.primary_kernel_ms, total_ms=self.total_ms,
-                    n_launches=self.n_launches, n_chunks=self.n_chunks)
+                    n_launches=self.n_launches, n_chunks=self.n_chunks, levels_ms=self.levels_ms)
 
 
 class Probe(C.Structure):

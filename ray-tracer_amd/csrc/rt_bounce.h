@@ -34,26 +34,33 @@ struct BounceArgs {
     R *fb;
     StatShard *stats;
 };
-// Wave `wave` of a workgroup asks for entry idx of sub-queue `sub` for every lane with `want`
-// set; the entry goes from memory straight into the wave's slice of `lds` (global_load_lds: no
-// vector registers are held while it is in flight), 16 bytes per lane and instruction.
+// LDS of a bounce workgroup: per wave a slice of `stride` chunks of 64 x 16 bytes.  Wave `wave`
+// asks for entry idx of sub-queue `sub` for every lane with `want` set; the entry goes from memory
+// straight into the first chunks of the wave's slice (global_load_lds: no vector registers are
+// held while it is in flight), 16 bytes per lane and instruction.
 template <typename R>
-RT_DEV void entry_prefetch(QueueChunk *lds, uint32_t wave, bool want, const QueueDev<R> &q, uint32_t sub, uint32_t idx)
+RT_DEV void entry_prefetch(QueueChunk *lds, uint32_t stride, uint32_t wave, bool want, const QueueDev<R> &q, uint32_t sub, uint32_t idx)
 {
     if (want) {
         const QueueChunk *src = reinterpret_cast<const QueueChunk *>(q.rec);
         for (uint32_t j = 0; j < kEntryChunks<R>; ++j)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + chunk_index(q, j, sub, idx)),
-                                             (__attribute__((address_space(3))) void *)(lds + (wave * kEntryChunks<R> + j) * 64u), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)(lds + (wave * stride + j) * 64u), 16, 0, 0);
     }
 }
 // ... and takes it out of LDS once it has arrived (each lane reads what was loaded for it).
 template <typename R>
-RT_DEV void entry_take(const QueueChunk *lds, uint32_t wave, uint32_t lane, bool want, V3<R> &o, V3<R> &d, R &weight, uint32_t &pixel)
+RT_DEV void entry_take(const QueueChunk *lds, uint32_t stride, uint32_t wave, uint32_t lane, bool want, V3<R> &o, V3<R> &d, R &weight,
+                       uint32_t &pixel)
 {
     if (want) {
+        // The transfers memory -> LDS count as vector memory operations: all of them have landed when
+        // that counter is zero.  Stated here and not left to the compiler, which orders an LDS read after
+        // such a transfer only where it can see that the two may touch the same bytes (it read two of the
+        // four chunks early once the sort above used the same array).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         QueueChunk c[kEntryChunks<R>];
-        for (uint32_t j = 0; j < kEntryChunks<R>; ++j) c[j] = lds[(wave * kEntryChunks<R> + j) * 64u + lane];
+        for (uint32_t j = 0; j < kEntryChunks<R>; ++j) c[j] = lds[(wave * stride + j) * 64u + lane];
         R v[8];
         __builtin_memcpy(v, c, sizeof v);
         o = { v[0], v[1], v[2] };
@@ -63,44 +70,121 @@ RT_DEV void entry_take(const QueueChunk *lds, uint32_t wave, uint32_t lane, bool
     }
 }
 
+// ---- regrouping the rays of a workgroup by the object they hit --------------------------------
+// The rays a wave takes from the queue have little to do with each other: after the closest-hit
+// walk its 64 lanes hold hits on half a dozen different objects (or none), and what follows --
+// normal by shape, pattern by type, reflection / refraction / Schlick by material, the specular
+// power, the shadow ray from that object's surface -- runs branch by branch with a few lanes
+// each.  Between the two phases the workgroup therefore sorts its rays by hit object: a counting
+// sort in LDS (one LDS atomic per ray for its rank within its bin, a 64-bin prefix sum per wave,
+// the ray and its hit written to their place and read back by the thread that owns that place).
+// Afterwards the lanes of a wave hold hits on the same object (two, where a wave straddles a bin
+// boundary), rays that hit nothing fill waves of their own at the end and skip the rest, and the
+// child rays are appended to the next queue in that order, so that the next level's waves start
+// from rays that left the same object.  Nothing else changes: the same rays, the same arithmetic
+// per ray, another thread.
+//
+// The sorted rays pass through the same LDS the queue entries are prefetched into: place p of the
+// sort is chunk slice p / 64, lane p % 64, and a wave's own places are its own slice.  A wave asks
+// for its next entries once it has read its places back; they arrive while it shades, and it takes
+// them before the next sort's barrier, after which any wave may write into the slice again.
+constexpr uint32_t kSortBins = 64;
+// chunks per wave slice: the entry's (origin, direction, weight, and t in place of the pixel word),
+// then {pixel, slot, object << 1 | holds a ray, hit_open}, then for scenes with transparency {top1, top2}
+template <typename R, bool SORT, bool TRACK> constexpr uint32_t kSliceChunks = kEntryChunks<R> + (SORT ? (TRACK ? 2u : 1u) : 0u);
+// Every thread of the workgroup calls this; `hist`: 2 x kSortBins counters, zero on the first
+// call, of which the calls use one and clear the other in turn (`round`).
+template <typename R, bool TRACK>
+RT_DEV void sort_by_hit_object(QueueChunk *lds, uint32_t *hist2, uint32_t round, bool &valid, V3<R> &ro, V3<R> &rd, R &weight,
+                               uint32_t &pixel, Hit<R> &h)
+{
+    constexpr uint32_t kStride = kSliceChunks<R, true, TRACK>, kE = kEntryChunks<R>;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t *hist = hist2 + (round & 1u) * kSortBins, *other = hist2 + ((round & 1u) ^ 1u) * kSortBins;
+    // bin: the object's index in World.objects (scenes handled here have few objects; indices past the
+    // bins share one), then the rays without a hit, then the lanes without a ray
+    const uint32_t key = !valid ? kSortBins - 1u : h.slot == kNone ? kSortBins - 2u : (h.obj < kSortBins - 3u ? h.obj : kSortBins - 3u);
+    const uint32_t rank = atomicAdd(&hist[key], 1u);
+    __syncthreads();
+    if (threadIdx.x < kSortBins) other[threadIdx.x] = 0u;  // for the next call: nobody reads it any more, nobody adds to it yet
+    // exclusive prefix sum over the bins, by every wave for itself
+    const uint32_t mine = hist[lane];
+    uint32_t incl = mine;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = __shfl_up(incl, off);
+        if ((int)lane >= off) incl += up;
+    }
+    const uint32_t at = __shfl(incl - mine, (int)key) + rank;
+    QueueChunk *dst = lds + (at >> 6) * kStride * 64u + (at & 63u);
+    {
+        const R v[8] = { ro.x, ro.y, ro.z, rd.x, rd.y, rd.z, weight, h.t };
+        QueueChunk c[kE];
+        __builtin_memcpy(c, v, sizeof v);
+        for (uint32_t j = 0; j < kE; ++j) dst[j * 64u] = c[j];
+        dst[kE * 64u] = QueueChunk{ { pixel, h.slot, (h.obj << 1) | (valid ? 1u : 0u), h.hit_open ? 1u : 0u } };
+        if constexpr (TRACK) dst[(kE + 1u) * 64u] = QueueChunk{ { h.top1, h.top2, 0u, 0u } };
+    }
+    __syncthreads();
+    const QueueChunk *src = lds + wave * kStride * 64u + lane;
+    QueueChunk c[kE];
+    for (uint32_t j = 0; j < kE; ++j) c[j] = src[j * 64u];
+    R v[8];
+    __builtin_memcpy(v, c, sizeof v);
+    ro = { v[0], v[1], v[2] };
+    rd = { v[3], v[4], v[5] };
+    weight = v[6];
+    h.t = v[7];
+    const QueueChunk tags = src[kE * 64u];
+    pixel = tags.w[0];
+    h.slot = tags.w[1];
+    valid = (tags.w[2] & 1u) != 0u;
+    h.obj = h.slot == kNone ? kNone : tags.w[2] >> 1;
+    h.hit_open = tags.w[3] != 0u;
+    if constexpr (TRACK) {
+        const QueueChunk tops = src[(kE + 1u) * 64u];
+        h.top1 = tops.w[0];
+        h.top2 = tops.w[1];
+    }
+    // what this wave read is in its registers before anything else may be written into its slice
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 // The loop's trip count is unknown to the compiler, which would otherwise move the literal
 // constants of the body (34 registers for the coefficients of pow alone) in front of it and
 // end up with 165 vector registers; the translation unit is therefore built without
 // machine-level invariant code motion (build.sh).
 //
 // Order of one round of the loop, chosen so that no memory latency is waited for:
-//   1. ask for the entries of the block after this one (memory -> LDS, nothing waits);
-//   2. closest hit and the child rays of this block's rays; the children are appended to the
-//      next level's queue at once (one atomic per wave for both kinds), which frees their
-//      registers for the shadow ray, whose walk covers the latency of the stores;
-//   3. shadow ray and lighting;
-//   4. take the next block's entries from LDS (they arrived long ago), then add this block's
+//   1. closest hit of this block's rays;
+//   2. (scenes walked object by object) the workgroup's rays regrouped by hit object;
+//   3. ask for the entries of the block after this one (memory -> LDS, nothing waits);
+//   4. the child rays, appended to the next level's queue at once (one atomic per wave for both
+//      kinds), which frees their registers for the shadow ray, whose walk covers the latency of
+//      the stores; shadow ray and lighting;
+//   5. take the next block's entries from LDS (they arrived long ago), then add this block's
 //      weight * lighting to the framebuffer: the atomics are in flight while the next round
 //      computes.
-#ifdef RTX_PHASE_CLOCK
-static __device__ unsigned int g_slow_flag;
-static __device__ unsigned long long g_slow_threshold = 3000000ull;  // cycles of a round above which its rays are kept
-static __device__ double g_slow_rays[64 * 8];
-#endif
 // COLD_LDS: the launch comes with cold_lds_bytes() of dynamic LDS and the scene has at most
 // kColdLdsObjects objects (launch_bounce sees to both).
-#ifndef RTX_WIDE_RAYS  // a level of at most this many rays gets one ray per wave (scenes with the sphere hierarchy)
-#define RTX_WIDE_RAYS 65536u
+#ifndef RTX_BOUNCE_SORT
+#define RTX_BOUNCE_SORT 1
 #endif
-#ifndef RTX_BOUNCE_ATTR  // occupancy experiments, e.g. -DRTX_BOUNCE_ATTR='__attribute__((amdgpu_waves_per_eu(5,5)))'
-#define RTX_BOUNCE_ATTR
-#endif
+constexpr uint32_t kWideRays = 65536u;  // a level of at most this many rays gets one ray per wave (scenes with the sphere hierarchy)
 template <typename R, uint32_t SF, bool COLD_LDS>
-__global__ void __launch_bounds__(bounce_block<R>(SF)) RTX_BOUNCE_ATTR
+__global__ void __launch_bounds__(bounce_block<R>(SF))
 k_bounce(BounceArgs<R> args_in_kernarg_segment)
 {
     constexpr uint32_t kPiece = bounce_block<R>(SF);  // rays per piece = threads per workgroup
-    __shared__ QueueChunk lds[kPiece * kEntryChunks<R>];
-#ifdef RTX_BOUNCE_LDS_PAD  // occupancy experiments: LDS nobody uses limits the workgroups per CU
-    __shared__ uint32_t lds_pad[RTX_BOUNCE_LDS_PAD / 4];
-    if (threadIdx.x == 0xffffffu) lds_pad[blockIdx.x] = 1u;
-    asm volatile("" :: "v"(lds_pad[threadIdx.x]));
-#endif
+    // Scenes walked object by object (no sphere hierarchy) regroup their rays by hit object between the two
+    // phases -- in f32.  Measured on a 4K frame of an 8-object scene with glass: 46 instead of 42 of 64 lanes
+    // active per vector instruction and 3 % fewer vector instructions in either precision, which the two
+    // barriers per round give back in f64 (1.84 against 1.82 ms; rounds are twice as long there and the waves of
+    // a workgroup drift further apart) and do not in f32 (1.165 against 1.185 ms).
+    constexpr bool kSort = RTX_BOUNCE_SORT != 0 && (SF & SF_CULL) == 0 && sizeof(R) == 4;
+    constexpr bool kTrack = (SF & SF_TRANSPARENT) != 0;
+    constexpr uint32_t kStride = kSliceChunks<R, kSort, kTrack>;
+    __shared__ QueueChunk lds[(kPiece / 64u) * kStride * 64u];
+    __shared__ uint32_t sort_hist[kSort ? 2u * kSortBins : 1u];
     const RT_CONSTANT_AS BounceArgs<R> *kp =
         (const RT_CONSTANT_AS BounceArgs<R> *)__builtin_amdgcn_kernarg_segment_ptr();
     const uint32_t sub_in = blockIdx.y;
@@ -108,22 +192,17 @@ k_bounce(BounceArgs<R> args_in_kernarg_segment)
     const uint32_t step = gridDim.x * kPiece;
     // one ray per wave for short levels: scenes with the sphere hierarchy whose rays carry no container
     // bookkeeping (that is kept per lane and not joined across lanes)
-    constexpr bool kWide = (SF & SF_CULL) != 0 && (SF & SF_TRANSPARENT) == 0 && !kLaneWalk;
-    constexpr uint32_t kWideRays = RTX_WIDE_RAYS;
-#ifdef RTX_LDS_TABLES
-    if constexpr ((SF & SF_CULL) == 0) stage_tables<R>(args_in_kernarg_segment.S);
-#endif
-    if constexpr (COLD_LDS) stage_cold_table<R>(args_in_kernarg_segment.S, kPiece);
+    constexpr bool kWide = (SF & SF_CULL) != 0 && (SF & SF_TRANSPARENT) == 0;
+    if constexpr (kSort) {
+        for (uint32_t i = threadIdx.x; i < 2u * kSortBins; i += kPiece) sort_hist[i] = 0u;
+        if constexpr (!COLD_LDS) __syncthreads();
+    }
+    if constexpr (COLD_LDS) stage_cold_table<R>(args_in_kernarg_segment.S, kPiece);  // ends with a barrier
+    uint32_t round = 0;
     V3<R> ro = { R(0), R(0), R(0) }, rd = ro;
     R weight = R(0);
     uint32_t pixel = 0;
     bool first = true;
-    RTX_PHASE_INIT();
-#ifdef RTX_PHASE_CLOCK
-    // one wave per launch compares the shader clock with the constant 100 MHz clock: the ratio
-    // is the frequency the chip ran at while this launch was resident
-    const unsigned long long clk0 = __builtin_readcyclecounter(), real0 = wall_clock64();
-#endif
     for (uint32_t base = blockIdx.x * kPiece;; base += step) {
         // the compiler must not know that kp is the same pointer as in the last round, or it
         // hoists every load from it out of the loop (some fifty scalar registers)
@@ -140,7 +219,7 @@ k_bounce(BounceArgs<R> args_in_kernarg_segment)
         // sub-queue's capacity rounded up to whole blocks, so the block indices, and with them
         // the bound on the output sub-queues, do not grow.
         uint32_t spread = 1u;
-        if constexpr ((SF & SF_CULL) != 0 && !kLaneWalk) {
+        if constexpr ((SF & SF_CULL) != 0) {
             const uint32_t budget = kSpreadLanes / gridDim.y;  // lanes per sub-queue when the chip is lightly loaded
             const uint64_t room = ((uint64_t)A.in_q.cap_sub + kPiece - 1) / kPiece * kPiece;
             while (spread < 64u && (uint64_t)n * (spread * 2u) <= budget && (uint64_t)n * (spread * 2u) <= room) spread *= 2u;
@@ -152,7 +231,7 @@ k_bounce(BounceArgs<R> args_in_kernarg_segment)
         }
         const bool wide = kWide && spread == 64u;  // wave-uniform
         const uint32_t total = n * spread;  // lane slots of this sub-queue
-        if (base >= total) break;
+        if (base >= total) break;  // (the same for every wave of the workgroup: the barriers below are met by all or none)
         auto slot_of = [&](uint32_t block_base, uint32_t &k) {
             const uint32_t lane_slot = block_base + threadIdx.x;
             k = lane_slot / spread;
@@ -161,179 +240,72 @@ k_bounce(BounceArgs<R> args_in_kernarg_segment)
         uint32_t k, k_next = 0;
         const bool valid = slot_of(base, k);
         if (first) {  // the first block of this workgroup: nothing was asked for in advance
-            entry_prefetch<R>(lds, wave, valid, A.in_q, sub_in, k);
-            entry_take<R>(lds, wave, lane, valid, ro, rd, weight, pixel);
+            entry_prefetch<R>(lds, kStride, wave, valid, A.in_q, sub_in, k);
+            entry_take<R>(lds, kStride, wave, lane, valid, ro, rd, weight, pixel);
             first = false;
         }
         const bool more = base + step < total;  // wave-uniform
         const bool valid_next = more && slot_of(base + step, k_next);
-        entry_prefetch<R>(lds, wave, valid_next, A.in_q, sub_in, k_next);
+        if constexpr (!kSort) entry_prefetch<R>(lds, kStride, wave, valid_next, A.in_q, sub_in, k_next);
 
-#ifdef RTX_PHASE_CLOCK
-        RTX_PHASE_BEGIN();
-#endif
         Node<R> nd;
         nd.hit = false;
         nd.has_reflect = nd.has_refract = false;
         nd.lighting = { R(0), R(0), R(0) };
         const uint32_t block = base / kPiece;
         const uint32_t sub = (block + sub_in) & A.out_q.sub_mask;
-        const R w = weight;
-        const uint32_t px_index = pixel;
-#ifdef RTX_PHASE_CLOCK
-        const V3<R> dbg_o = ro, dbg_d = rd;
-#endif
-        bool done = false;
-        if constexpr (kWide) {
-            if (wide) {
-                // the wave's one ray sits in lane 0 (the lane slots of a ray start at a multiple of 64):
-                // every lane gets it, every lane computes the same node, lane 0 alone acts on it
-                auto all = [](R v) {
-                    if constexpr (sizeof(R) == 8) {
-                        const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
-                        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
-                        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
-                        return __builtin_bit_cast(R, ((unsigned long long)hi << 32) | lo);
-                    } else {
-                        return __builtin_bit_cast(R, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
-                    }
-                };
-                if (__ballot(valid) != 0ull) {
-                    const V3<R> o = { all(ro.x), all(ro.y), all(ro.z) }, d = { all(rd.x), all(rd.y), all(rd.z) };
-                    nd = trace_node<R, SF, false, WALK_WIDE, COLD_LDS>(A.S, nullptr, o, d, A.remaining, [&](const Node<R> &c) {
-                        queue_push2(A.out_q, sub, c.has_reflect && lane == 0u, c.over_point, c.reflectv, w * c.reflect_factor,
-                                    c.has_refract && lane == 0u, c.under_point, c.refract_dir, w * c.refract_factor, px_index);
-                    });
+        R w = weight;
+        uint32_t px_index = pixel;
+        bool live = valid;  // this thread holds a ray in the second phase (after regrouping: not the one it loaded)
+        auto push_children = [&](const Node<R> &c) {
+            queue_push2(A.out_q, sub, c.has_reflect, c.over_point, c.reflectv, w * c.reflect_factor, c.has_refract,
+                        c.under_point, c.refract_dir, w * c.refract_factor, px_index);
+        };
+        if constexpr (kSort) {
+            Hit<R> h;
+            h.t = Num<R>::inf;
+            h.slot = h.obj = kNone;
+            h.hit_open = false;
+            h.top1 = h.top2 = kNone;
+            h.top1_t = h.top2_t = -Num<R>::inf;
+            if (valid) h = closest_hit<R, kTrack, false, (SF & SF_CHAIN) != 0, WALK_WAVE, COLD_LDS>(A.S, ro, rd, Num<R>::inf);
+            sort_by_hit_object<R, kTrack>(lds, sort_hist, round++, live, ro, rd, w, px_index, h);
+            entry_prefetch<R>(lds, kStride, wave, valid_next, A.in_q, sub_in, k_next);
+            if (live) nd = shade_node<R, SF, false, WALK_WAVE, COLD_LDS>(A.S, ro, rd, A.remaining, h, push_children);
+        } else if (kWide && wide) {
+            // the wave's one ray sits in lane 0 (the lane slots of a ray start at a multiple of 64):
+            // every lane gets it, every lane computes the same node, lane 0 alone acts on it
+            auto all = [](R v) {
+                if constexpr (sizeof(R) == 8) {
+                    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+                    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+                    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
+                    return __builtin_bit_cast(R, ((unsigned long long)hi << 32) | lo);
+                } else {
+                    return __builtin_bit_cast(R, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
                 }
-                done = true;
+            };
+            if (__ballot(valid) != 0ull) {
+                const V3<R> o = { all(ro.x), all(ro.y), all(ro.z) }, d = { all(rd.x), all(rd.y), all(rd.z) };
+                nd = trace_node<R, SF, false, kWide ? WALK_WIDE : WALK_WAVE, COLD_LDS>(A.S, nullptr, o, d, A.remaining, [&](const Node<R> &c) {
+                    queue_push2(A.out_q, sub, c.has_reflect && lane == 0u, c.over_point, c.reflectv, w * c.reflect_factor,
+                                c.has_refract && lane == 0u, c.under_point, c.refract_dir, w * c.refract_factor, px_index);
+                });
             }
+        } else if (valid) {
+            nd = trace_node<R, SF, false, WALK_WAVE, COLD_LDS>(A.S, nullptr, ro, rd, A.remaining, push_children);
         }
-        if (!done && valid) {
-            nd = trace_node<R, SF, false, (kLaneWalk && (SF & SF_CULL) != 0) ? WALK_LANE : WALK_WAVE, COLD_LDS>(A.S, nullptr, ro, rd, A.remaining, [&](const Node<R> &c) {
-                queue_push2(A.out_q, sub, c.has_reflect, c.over_point, c.reflectv, w * c.reflect_factor, c.has_refract,
-                            c.under_point, c.refract_dir, w * c.refract_factor, px_index);
-            });
-        }
-        count_hits(A.stats, block + sub_in, A.level, valid && nd.hit);
-        entry_take<R>(lds, wave, lane, valid_next, ro, rd, weight, pixel);
-#ifdef RTX_EXP_NO_FB_ADD  // knock-out experiment: the frame is wrong, the time shows what the atomics cost
-        if (valid && nd.hit && nd.lighting.x * w == R(-12345)) {
-#else
-        if (valid && nd.hit) {
-#endif
+        count_hits(A.stats, block + sub_in, A.level, live && nd.hit);
+        entry_take<R>(lds, kStride, wave, lane, valid_next, ro, rd, weight, pixel);
+        if (live && nd.hit) {
             R *px = A.fb + (size_t)px_index * 3;
             fb_add<R>(px + 0, nd.lighting.x * w);
             fb_add<R>(px + 1, nd.lighting.y * w);
             fb_add<R>(px + 2, nd.lighting.z * w);
         }
-#ifdef RTX_PHASE_CLOCK
-        {   // the longest round of any wave (a whole color_at node for 64 rays), and how many took over 100 000 cycles
-            const unsigned long long took = __builtin_readcyclecounter() - phase_t_;
-            if (phase_leader()) {
-                atomicMax(&g_phase[13], took);
-                if (took > 100000ull) atomicAdd(&g_phase[12], 1ull);
-            }
-            // the rays of the first wave whose round took over g_slow_threshold cycles
-            unsigned int claimed = 1u;
-            if (took > g_slow_threshold && phase_leader()) claimed = atomicCAS(&g_slow_flag, 0u, 1u);
-            claimed = __shfl(claimed, (int)(__ffsll((long long)__ballot(1)) - 1));
-            if (took > g_slow_threshold && claimed == 0u) {
-                double *o = g_slow_rays + (threadIdx.x & 63u) * 8;
-                o[0] = dbg_o.x; o[1] = dbg_o.y; o[2] = dbg_o.z; o[3] = dbg_d.x; o[4] = dbg_d.y; o[5] = dbg_d.z;
-                o[6] = valid ? 1.0 : 0.0; o[7] = (double)took;
-            }
-        }
-        RTX_PHASE_MARK(5);  // a whole round, for the waves that reach here converged
-#endif
         if (!more) break;
     }
-#ifdef RTX_PHASE_CLOCK
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-        atomicAdd(&g_phase[14], __builtin_readcyclecounter() - clk0);
-        atomicAdd(&g_phase[15], wall_clock64() - real0);
-    }
-#endif
-    RTX_PHASE_FLUSH();
 }
-
-#ifdef RTX_SPLIT_BOUNCE
-// Experiment (tools build, -DRTX_SPLIT_BOUNCE; measured on a 4K frame of an 8-object scene with glass: 208 + 314 us
-// per level for the two kernels against 371 us for the fused one, the same vector instructions at twice the occupancy):
-// one recursion level as two launches with the hit record in memory between them -- the
-// intersect kernel finds every queued ray's closest hit, the shade kernel does the rest of the
-// color_at node.  One ray per thread, grids that cover the queues' capacity.
-template <typename R>
-struct alignas(16) HitRec {
-    R t;
-    uint32_t slot, obj, top1, top2, open, pad;
-};
-template <typename R>
-RT_DEV void entry_load(const QueueDev<R> &q, uint32_t sub, uint32_t idx, V3<R> &o, V3<R> &d, R &weight, uint32_t &pixel)
-{
-    const QueueChunk *src = reinterpret_cast<const QueueChunk *>(q.rec);
-    QueueChunk c[kEntryChunks<R>];
-    for (uint32_t j = 0; j < kEntryChunks<R>; ++j) c[j] = src[chunk_index(q, j, sub, idx)];
-    R v[8];
-    __builtin_memcpy(v, c, sizeof v);
-    o = { v[0], v[1], v[2] };
-    d = { v[3], v[4], v[5] };
-    weight = v[6];
-    pixel = pixel_bits_load<R>(v[7]);
-}
-template <typename R, uint32_t SF>
-__global__ void __launch_bounds__(bounce_block<R>(SF)) k_split_intersect(BounceArgs<R> A, HitRec<R> *__restrict__ hits)
-{
-    const uint32_t sub = blockIdx.y;
-    uint32_t n = ro_load(A.in_q.count + (size_t)sub * kCountStride);
-    if (n > A.in_q.cap_sub) n = A.in_q.cap_sub;
-    if (blockIdx.x * bounce_block<R>(SF) >= n) return;
-    const uint32_t k = blockIdx.x * bounce_block<R>(SF) + threadIdx.x;
-    if (k >= n) return;
-    V3<R> ro, rd;
-    R weight;
-    uint32_t pixel;
-    entry_load(A.in_q, sub, k, ro, rd, weight, pixel);
-    const Hit<R> h = closest_hit<R, (SF & SF_TRANSPARENT) != 0, (SF & SF_CULL) != 0, (SF & SF_CHAIN) != 0>(A.S, ro, rd, Num<R>::inf);
-    HitRec<R> out = { h.t, h.slot, h.obj, h.top1, h.top2, h.hit_open ? 1u : 0u, 0u };
-    hits[(size_t)sub * A.in_q.cap_sub + k] = out;
-}
-template <typename R, uint32_t SF>
-__global__ void __launch_bounds__(bounce_block<R>(SF)) k_split_shade(BounceArgs<R> A, const HitRec<R> *__restrict__ hits)
-{
-    const uint32_t sub_in = blockIdx.y;
-    uint32_t n = ro_load(A.in_q.count + (size_t)sub_in * kCountStride);
-    if (n > A.in_q.cap_sub) n = A.in_q.cap_sub;
-    if (blockIdx.x * bounce_block<R>(SF) >= n) return;
-    const uint32_t k = blockIdx.x * bounce_block<R>(SF) + threadIdx.x;
-    const bool valid = k < n;
-    Node<R> nd;
-    nd.hit = false;
-    nd.has_reflect = nd.has_refract = false;
-    nd.lighting = { R(0), R(0), R(0) };
-    R weight = R(0);
-    uint32_t pixel = 0;
-    const uint32_t sub = (blockIdx.x + sub_in) & A.out_q.sub_mask;
-    if (valid) {
-        V3<R> ro, rd;
-        entry_load(A.in_q, sub_in, k, ro, rd, weight, pixel);
-        const HitRec<R> r = hits[(size_t)sub_in * A.in_q.cap_sub + k];
-        Hit<R> h;
-        h.t = r.t; h.slot = r.slot; h.obj = r.obj; h.top1 = r.top1; h.top2 = r.top2; h.hit_open = r.open != 0u;
-        h.top1_t = h.top2_t = R(0);
-        nd = shade_node<R, SF, false, WALK_WAVE, false>(A.S, ro, rd, A.remaining, h, [&](const Node<R> &c) {
-            queue_push2(A.out_q, sub, c.has_reflect, c.over_point, c.reflectv, weight * c.reflect_factor, c.has_refract, c.under_point,
-                        c.refract_dir, weight * c.refract_factor, pixel);
-        });
-        if (nd.hit) {
-            R *px = A.fb + (size_t)pixel * 3;
-            fb_add<R>(px + 0, nd.lighting.x * weight);
-            fb_add<R>(px + 1, nd.lighting.y * weight);
-            fb_add<R>(px + 2, nd.lighting.z * weight);
-        }
-    }
-    count_hits(A.stats, blockIdx.x + sub_in, A.level, valid && nd.hit);
-}
-#endif
 
 template <typename R>
 hipError_t launch_bounce(uint32_t sf, hipStream_t stream, const SceneDev<R> &scene, const QueueDev<R> &in_q,
@@ -347,49 +319,18 @@ hipError_t launch_bounce(uint32_t sf, hipStream_t stream, const SceneDev<R> &sce
     const uint32_t share = resident_blocks / n_sub > 0 ? resident_blocks / n_sub : 1u;
     const dim3 grid(worst < share ? worst : share, n_sub);
     const BounceArgs<R> args = { scene, in_q, out_q, remaining, level, fb, stats };
-#ifdef RTX_SPLIT_BOUNCE
-    {
-        static void *hit_buffer = nullptr;  // experiment: one buffer for the process, never shrunk (single-threaded use)
-        static size_t hit_bytes = 0;
-        const size_t need = (size_t)n_sub * in_q.cap_sub * sizeof(HitRec<R>);
-        if (need > hit_bytes) {
-            (void)hipDeviceSynchronize();
-            if (hit_buffer) (void)hipFree(hit_buffer);
-            hit_buffer = nullptr;
-            hit_bytes = 0;
-            const hipError_t e = hipMalloc(&hit_buffer, need);
-            if (e != hipSuccess) return e;
-            hit_bytes = need;
-        }
-        const dim3 full(worst, n_sub);
-        HitRec<R> *hits = static_cast<HitRec<R> *>(hit_buffer);
-#define RTX_CALL(SFV)                                                                                   \
-    if constexpr (((SFV) & (SF_REFLECTIVE | SF_TRANSPARENT)) != 0) {                                    \
-        hipLaunchKernelGGL((k_split_intersect<R, SFV | SF_PATTERN>), full, dim3(piece), 0, stream, args, hits); \
-        hipLaunchKernelGGL((k_split_shade<R, SFV | SF_PATTERN>), full, dim3(piece), 0, stream, args, hits);     \
-    }
-        RTX_SF_SWITCH(sf, RTX_CALL)
-#undef RTX_CALL
-        return hipGetLastError();
-    }
-#endif
     // Scenes small enough keep their shading table in LDS; only the variants without bounding-sphere
     // tests exist in that form (a scene with those tests has at least 16 objects and usually thousands).
-    const uint32_t cold_bytes =
-#ifdef RTX_LDS_TABLES
-        0u;  // that experiment uses the dynamic LDS for the intersection tables
-#else
-        (sf & SF_CULL) ? 0u : cold_lds_bytes<R>(scene.n);
-#endif
+    const uint32_t cold_bytes = (sf & SF_CULL) ? 0u : cold_lds_bytes<R>(scene.n);
 #define RTX_CALL(SFV)                                                                                   \
     if constexpr (((SFV) & (SF_REFLECTIVE | SF_TRANSPARENT)) != 0) {                                    \
         if constexpr (((SFV) & SF_CULL) == 0) {                                                         \
             if (cold_bytes)                                                                             \
                 hipLaunchKernelGGL((k_bounce<R, SFV | SF_PATTERN, true>), grid, dim3(piece), cold_bytes, stream, args); \
             else                                                                                        \
-                hipLaunchKernelGGL((k_bounce<R, SFV | SF_PATTERN, false>), grid, dim3(piece), table_lds_bytes(scene), stream, args); \
+                hipLaunchKernelGGL((k_bounce<R, SFV | SF_PATTERN, false>), grid, dim3(piece), 0, stream, args); \
         } else {                                                                                        \
-            hipLaunchKernelGGL((k_bounce<R, SFV | SF_PATTERN, false>), grid, dim3(piece), table_lds_bytes(scene), stream, args); \
+            hipLaunchKernelGGL((k_bounce<R, SFV | SF_PATTERN, false>), grid, dim3(piece), 0, stream, args); \
         }                                                                                               \
     }
     RTX_SF_SWITCH(sf, RTX_CALL)

@@ -1159,6 +1159,8 @@ int collect_stats(rtx_context *ctx, Slot *slot, uint32_t n_chunks, uint64_t n_pr
         stats->kernel_ms = ms;
         HIP_TRY(hipEventElapsedTime(&ms, slot->ev[2], slot->ev[3]));
         stats->primary_kernel_ms = ms;
+        HIP_TRY(hipEventElapsedTime(&ms, slot->ev[3], slot->ev[1]));
+        stats->levels_ms = ms;
     }
     return RTX_OK;
 }

@@ -212,10 +212,10 @@ int rtx_multi_render(rtx_multi *m, const rtx_multi_scene *scene, const rtx_camer
     std::vector<rtx_stats> counted(n);
     const bool count = stats && (flags & RTX_MULTI_COUNT_RAYS);
     // every GPU: its bands, then one strided copy that drops them into the frame
-    for (uint32_t k = 0; k < n; ++k) {
+    auto enqueue = [&](uint32_t k) -> int {
         Device &d = m->dev[k];
         const uint32_t rows = rtx_part_rows(H, band, n, k);
-        if (rows == 0) continue;
+        if (rows == 0) return RTX_OK;
         MULTI_HIP(hipSetDevice(d.id));
         int rc = grow(&d.part, &d.part_bytes, (size_t)rows * row_bytes);
         if (rc) return rc;
@@ -233,11 +233,32 @@ int rtx_multi_render(rtx_multi *m, const rtx_multi_scene *scene, const rtx_camer
             MULTI_HIP(hipMemcpyAsync(dst + (size_t)whole * n * band_bytes, (char *)d.part + (size_t)whole * band_bytes,
                                      (size_t)rest * row_bytes, hipMemcpyDeviceToDevice, d.stream));
         MULTI_HIP(hipEventRecord(d.done, d.stream));
+        return RTX_OK;
+    };
+    // A failure on one GPU must not return while the others still render and copy into `out`: the caller may
+    // free it.  Everything started so far (the failing GPU included) is waited for first; the first error is kept.
+    auto drain = [&](uint32_t started) {
+        const std::string first = tl_multi_error;
+        for (uint32_t j = 0; j < started; ++j) {
+            Device &d = m->dev[j];
+            if (hipSetDevice(d.id) != hipSuccess) continue;
+            (void)hipStreamSynchronize(d.stream);
+            (void)rtx_context_synchronize(d.ctx);
+        }
+        (void)hipGetLastError();
+        tl_multi_error = first;
+    };
+    for (uint32_t k = 0; k < n; ++k) {
+        const int rc = enqueue(k);
+        if (rc) {
+            drain(k + 1);
+            return rc;
+        }
     }
     double render_ms = 0.0, gather_ms = 0.0;
-    for (uint32_t k = 0; k < n; ++k) {
+    auto wait_for = [&](uint32_t k) -> int {
         Device &d = m->dev[k];
-        if (rtx_part_rows(H, band, n, k) == 0) continue;
+        if (rtx_part_rows(H, band, n, k) == 0) return RTX_OK;
         MULTI_HIP(hipSetDevice(d.id));
         MULTI_HIP(hipEventSynchronize(d.done));
         if (stats) {
@@ -249,11 +270,21 @@ int rtx_multi_render(rtx_multi *m, const rtx_multi_scene *scene, const rtx_camer
             stats->color_rays += counted[k].color_rays;
             stats->shadow_rays += counted[k].shadow_rays;
         }
+        return RTX_OK;
+    };
+    for (uint32_t k = 0; k < n; ++k) {
+        const int rc = wait_for(k);
+        if (rc) {
+            drain(n);
+            return rc;
+        }
     }
-    for (uint32_t k = 0; k < n; ++k) {  // an overflow of a ray queue on any GPU spoils the frame
+    int overflow = RTX_OK;
+    for (uint32_t k = 0; k < n; ++k) {  // an overflow of a ray queue on any GPU spoils the frame (every GPU is asked: the report clears it)
         const int rc = rtx_context_synchronize(m->dev[k].ctx);
-        if (rc) return forward(rc, m->dev[k].id);
+        if (rc && !overflow) overflow = forward(rc, m->dev[k].id);
     }
+    if (overflow) return overflow;
     if (!out_on_first_device) {
         MULTI_HIP(hipSetDevice(m->dev[0].id));
         MULTI_HIP(hipMemcpy(out, frame, need, hipMemcpyDeviceToHost));

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(rta):
 
 
 def test_struct_layouts_match_header(rta):
-    assert ctypes.sizeof(rta.Stats) == 8 + 8 + 64 + 24 + 8
+    assert ctypes.sizeof(rta.Stats) == 8 + 8 + 64 + 24 + 8 + 8
     assert ctypes.sizeof(rta.Probe) == 8 * 21 + 16
     assert ctypes.sizeof(rta.CameraDesc) == 8 + 128 + 24
 

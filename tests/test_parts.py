@@ -1,6 +1,8 @@
 """Frames rendered in parts (rtx_render_part_device): the bands of 10 rows dealt out in turn to
 several GPUs, as values or as 8-bit pixels converted on the device, reassembled here on the host
 and compared with the whole frame."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -132,6 +134,45 @@ def test_several_gpus_behind_the_c_abi(rta, orc, scene_name, W, H, ids):
         assert st["gather_bytes"] == (H - part0) * W * 4
         with pytest.raises(rta.MultiError, match="too small"):
             multi.render(ms, cd, 5, rta.F64, 0, got.ctypes.data, got.nbytes - 8)
+    finally:
+        buf.free()
+        rta.rtx_multi_scene_destroy(ms)
+        multi.close()
+        scene.close()
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_two_different_gpus_behind_the_c_abi(rta, orc):
+    """rtx_multi_* on two physical GPUs (peer copies over xGMI, or through host memory where the GPUs
+    cannot reach each other): the frame equals the one GPU's, as values and as RGBA8.  Skipped on a
+    box with one GPU: there the same code runs with one GPU named several times (above)."""
+    hip = hiprt.runtime()
+    count = C.c_int(0)
+    assert hip.hipGetDeviceCount(C.byref(count)) == 0
+    if count.value < 2:
+        pytest.skip("needs two GPUs")
+    from ray_tracer_amd import scenes
+    W, H = 640, 367
+    w, cam = scenes.glass_scene(rta.api, W, H)
+    flat = rta.flatten(w)
+    cd = rta.camera_desc(cam)
+    ctx = rta.Context(0)
+    scene = rta.Scene(ctx, flat)
+    whole = np.empty((H, W, 3))
+    rta._check(rta.rtx_render(ctx.h, scene.h, cd, 5, rta.F64, 0, H, whole.ctypes.data, whole.nbytes, None, None, None))
+    multi = rta.Multi([0, 1])
+    ms = multi.upload(flat)
+    buf = hiprt.Buffer(hip, W * H * 4)
+    try:
+        got = np.zeros((H, W, 3))
+        multi.render(ms, cd, 5, rta.F64, 0, got.ctypes.data, got.nbytes)
+        assert np.abs(got - whole).max() <= 1e-12
+        buf.fill(0x11)
+        multi.render(ms, cd, 5, rta.F64, rta.PIXELS_RGBA8, buf.ptr.value, W * H * 4, on_device=True)
+        rgba = buf.read((H, W, 4), np.uint8)
+        diff = np.abs(rgba[..., :3].astype(int) - orc.quantize_u8(whole).astype(int))
+        assert diff.max() <= 1 and (diff != 0).mean() < 1e-3
     finally:
         buf.free()
         rta.rtx_multi_scene_destroy(ms)
