@@ -19,7 +19,7 @@ k_probe(SceneDev<double> S, const double *__restrict__ rays, uint32_t n, rtx_pro
     for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < n; k += stride) {
         const double *r = rays + (size_t)k * 6;
         V3<double> ro = { r[0], r[1], r[2] }, rd = { r[3], r[4], r[5] };
-        Node<double> nd = trace_node<double, SF, false>(S, nullptr, ro, rd, 5u);
+        Node<double> nd = trace_node<double, SF, false, WALK_WAVE, false, true>(S, nullptr, ro, rd, 5u);
         rtx_probe p;
         __builtin_memset(&p, 0, sizeof p);
         p.t = -1.0;
@@ -159,19 +159,3 @@ template struct Launch<double>;
 
 }  // namespace rtx
 
-#ifdef RTX_PHASE_CLOCK
-extern "C" int rtx_debug_phase(unsigned long long *out, int reset)
-{
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rtx::g_phase), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(rtx::g_phase), z, sizeof z) != hipSuccess) return -1; }
-    return 0;
-}
-#endif
-#ifdef RTX_COUNT_WALK
-extern "C" int rtx_debug_walk(unsigned long long *out, int reset)
-{
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rtx::g_walk), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(rtx::g_walk), z, sizeof z) != hipSuccess) return -1; }
-    return 0;
-}
-#endif

@@ -190,9 +190,8 @@ k_bounce(BounceArgs<R> args_in_kernarg_segment)
     const uint32_t sub_in = blockIdx.y;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t step = gridDim.x * kPiece;
-    // one ray per wave for short levels: scenes with the sphere hierarchy whose rays carry no container
-    // bookkeeping (that is kept per lane and not joined across lanes)
-    constexpr bool kWide = (SF & SF_CULL) != 0 && (SF & SF_TRANSPARENT) == 0;
+    // one ray per wave for short levels of scenes with the sphere hierarchy
+    constexpr bool kWide = (SF & SF_CULL) != 0;
     if constexpr (kSort) {
         for (uint32_t i = threadIdx.x; i < 2u * kSortBins; i += kPiece) sort_hist[i] = 0u;
         if constexpr (!COLD_LDS) __syncthreads();
@@ -307,10 +306,124 @@ k_bounce(BounceArgs<R> args_in_kernarg_segment)
     }
 }
 
+// One recursion level of a scene whose packed sphere hierarchy fits LDS (SF_LANE_TREE): every lane
+// walks the hierarchy for its own ray (lane_tree_walk_table).  A workgroup copies the hierarchy into
+// LDS once and then loops over its share of the sub-queue's rays, kLaneTreeBlock at a time, its
+// waves running free of each other; the entries are read straight from the queue (the LDS is taken).
+// The same queues, the same rule for where the children of a block go, as k_bounce.
+template <typename R>
+RT_DEV void entry_load(const QueueDev<R> &q, uint32_t sub, uint32_t idx, V3<R> &o, V3<R> &d, R &weight, uint32_t &pixel)
+{
+    const QueueChunk *src = reinterpret_cast<const QueueChunk *>(q.rec);
+    QueueChunk c[kEntryChunks<R>];
+    for (uint32_t j = 0; j < kEntryChunks<R>; ++j) c[j] = src[chunk_index(q, j, sub, idx)];
+    R v[8];
+    __builtin_memcpy(v, c, sizeof v);
+    o = { v[0], v[1], v[2] };
+    d = { v[3], v[4], v[5] };
+    weight = v[6];
+    pixel = pixel_bits_load<R>(v[7]);
+}
+#ifndef RTX_TREE_WIDE_RAYS
+#define RTX_TREE_WIDE_RAYS 131072u
+#endif
+#ifndef RTX_TREE_WIDE_RAYS_GLASS
+#define RTX_TREE_WIDE_RAYS_GLASS 4096u
+#endif
+constexpr uint32_t kTreeWideRays = RTX_TREE_WIDE_RAYS, kTreeWideRaysGlass = RTX_TREE_WIDE_RAYS_GLASS;  // a level of at most this many rays gets one ray per wave here
+template <typename R, uint32_t SF, int WALK>
+__global__ void __launch_bounds__(kLaneTreeBlock)
+k_bounce_tree(BounceArgs<R> args_in_kernarg_segment)
+{
+    static_assert((SF & SF_CULL) != 0, "scenes with the sphere hierarchy");
+    constexpr uint32_t kPiece = kLaneTreeBlock;
+    __shared__ __attribute__((aligned(16))) unsigned long long tree[kLaneTreeMaxNodes];
+    const RT_CONSTANT_AS BounceArgs<R> *kp =
+        (const RT_CONSTANT_AS BounceArgs<R> *)__builtin_amdgcn_kernarg_segment_ptr();
+    const uint32_t sub_in = blockIdx.y;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t step = gridDim.x * kPiece;
+    {   // a workgroup without rays leaves before it copies anything
+        uint32_t n = ro_load(args_in_kernarg_segment.in_q.count + (size_t)sub_in * kCountStride);
+        if (n > args_in_kernarg_segment.in_q.cap_sub) n = args_in_kernarg_segment.in_q.cap_sub;
+        if ((uint64_t)blockIdx.x * kPiece >= (uint64_t)n * 64u) return;
+    }
+    stage_lane_tree<R>(args_in_kernarg_segment.S, (RT_LDS_AS unsigned long long *)tree, kPiece);
+    for (uint32_t base = blockIdx.x * kPiece;; base += step) {
+        asm volatile("" : "+s"(kp));  // see k_bounce
+        BounceArgs<R> A;
+        __builtin_memcpy(&A, kp, sizeof A);
+        A.S.q_lds = (uint32_t)(uintptr_t)(RT_LDS_AS unsigned long long *)tree;
+        uint32_t n = ro_load(A.in_q.count + (size_t)sub_in * kCountStride);
+        if (n > A.in_q.cap_sub) n = A.in_q.cap_sub;
+        // a short level: one ray per wave, the 64 lanes side by side on the hierarchy (see k_bounce; n * 64 lane
+        // slots stay within the sub-queue's capacity in whole blocks, so the bound on the output sub-queues holds)
+        const uint64_t room = ((uint64_t)A.in_q.cap_sub + kPiece - 1) / kPiece * kPiece;
+        constexpr uint32_t kWideBelow = (SF & SF_TRANSPARENT) ? kTreeWideRaysGlass : kTreeWideRays;
+        const bool wide = (uint64_t)n * gridDim.y <= kWideBelow && (uint64_t)n * 64u <= room;
+        // Between the two, a level that does not fill the chip's lanes gets one ray per 2, 4 ... lanes: a wave
+        // takes as long as the slowest of its rays, and there are wave slots to spare.
+        uint32_t spread = 1u;
+        if (wide) {
+            spread = 64u;
+        } else {
+            const uint32_t budget = kSpreadLanes / gridDim.y;
+            while (spread < 16u && (uint64_t)n * (spread * 2u) <= budget && (uint64_t)n * (spread * 2u) <= room) spread *= 2u;
+        }
+        const uint32_t total = n * spread;
+        if (base >= total) break;
+        const uint32_t lane_slot = base + threadIdx.x;
+        const uint32_t k = lane_slot / spread;
+        const bool valid = k < n && (lane_slot & (spread - 1u)) == 0u;
+        Node<R> nd;
+        nd.hit = false;
+        nd.has_reflect = nd.has_refract = false;
+        nd.lighting = { R(0), R(0), R(0) };
+        const uint32_t block = base / kPiece;
+        const uint32_t sub = (block + sub_in) & A.out_q.sub_mask;
+        R w = R(0);
+        uint32_t px_index = 0;
+        V3<R> ro = { R(0), R(0), R(0) }, rd = ro;
+        if (valid) entry_load<R>(A.in_q, sub_in, k, ro, rd, w, px_index);
+        if (wide) {
+            auto all = [](R v) {
+                if constexpr (sizeof(R) == 8) {
+                    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+                    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+                    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
+                    return __builtin_bit_cast(R, ((unsigned long long)hi << 32) | lo);
+                } else {
+                    return __builtin_bit_cast(R, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+                }
+            };
+            if (__ballot(valid) != 0ull) {  // the wave's one ray sits in lane 0
+                const V3<R> o = { all(ro.x), all(ro.y), all(ro.z) }, d = { all(rd.x), all(rd.y), all(rd.z) };
+                nd = trace_node<R, SF, false, WALK_TREE_WIDE, false>(A.S, nullptr, o, d, A.remaining, [&](const Node<R> &c) {
+                    queue_push2(A.out_q, sub, c.has_reflect && lane == 0u, c.over_point, c.reflectv, w * c.reflect_factor,
+                                c.has_refract && lane == 0u, c.under_point, c.refract_dir, w * c.refract_factor, px_index);
+                });
+            }
+        } else if (valid) {
+            nd = trace_node<R, SF, false, WALK, false>(A.S, nullptr, ro, rd, A.remaining, [&](const Node<R> &c) {
+                queue_push2(A.out_q, sub, c.has_reflect, c.over_point, c.reflectv, w * c.reflect_factor, c.has_refract,
+                            c.under_point, c.refract_dir, w * c.refract_factor, px_index);
+            });
+        }
+        count_hits(A.stats, block + sub_in, A.level, valid && nd.hit);
+        if (valid && nd.hit) {
+            R *px = A.fb + (size_t)px_index * 3;
+            fb_add<R>(px + 0, nd.lighting.x * w);
+            fb_add<R>(px + 1, nd.lighting.y * w);
+            fb_add<R>(px + 2, nd.lighting.z * w);
+        }
+        if ((uint64_t)base + step >= total) break;
+    }
+}
+
 template <typename R>
 hipError_t launch_bounce(uint32_t sf, hipStream_t stream, const SceneDev<R> &scene, const QueueDev<R> &in_q,
                              const QueueDev<R> &out_q, uint32_t remaining, uint32_t level, R *fb, StatShard *stats,
-                             uint32_t resident_blocks, uint32_t longest)
+                             uint32_t resident_blocks, uint32_t longest, int tree_walk)
 {
     if ((sf & (SF_REFLECTIVE | SF_TRANSPARENT)) == 0 || in_q.cap_sub == 0) return hipSuccess;  // nothing can be queued
     const uint32_t n_sub = in_q.sub_mask + 1;
@@ -319,6 +432,18 @@ hipError_t launch_bounce(uint32_t sf, hipStream_t stream, const SceneDev<R> &sce
     const uint32_t share = resident_blocks / n_sub > 0 ? resident_blocks / n_sub : 1u;
     const dim3 grid(worst < share ? worst : share, n_sub);
     const BounceArgs<R> args = { scene, in_q, out_q, remaining, level, fb, stats };
+    if (sf & SF_LANE_TREE) {
+        if (scene.q_n == 0 || scene.q_n > kLaneTreeMaxNodes || !scene.q_nodes) return hipErrorInvalidValue;
+#define RTX_CALL(SFV)                                                                                   \
+    if constexpr (((SFV) & (SF_REFLECTIVE | SF_TRANSPARENT)) != 0 && ((SFV) & SF_CULL) != 0)            \
+    {                                                                                                   \
+        if (tree_walk == WALK_LANE) hipLaunchKernelGGL((k_bounce_tree<R, SFV | SF_PATTERN, WALK_LANE>), grid, dim3(piece), 0, stream, args); \
+        else hipLaunchKernelGGL((k_bounce_tree<R, SFV | SF_PATTERN, WALK_TREE>), grid, dim3(piece), 0, stream, args); \
+    }
+        RTX_SF_SWITCH(sf, RTX_CALL)
+#undef RTX_CALL
+        return hipGetLastError();
+    }
     // Scenes small enough keep their shading table in LDS; only the variants without bounding-sphere
     // tests exist in that form (a scene with those tests has at least 16 objects and usually thousands).
     const uint32_t cold_bytes = (sf & SF_CULL) ? 0u : cold_lds_bytes<R>(scene.n);

@@ -17,12 +17,6 @@
 #include "rt_types.h"
 
 #define RT_DEV __device__ __forceinline__
-// Table walks may fetch record i+1 while record i is in use.  That doubles the scalar registers
-// a record occupies, and the spills this causes cost more than the latency it hides (measured:
-// 83 -> 70 us on the default 4K frame, 364 -> 324 ms on the 10k-object scene), so it is off.
-#ifndef RTX_WALK_PREFETCH
-#define RTX_WALK_PREFETCH 0
-#endif
 
 namespace rtx {
 
@@ -532,14 +526,6 @@ RT_DEV bool may_hit(const BoundRec<R> &b, const CullRay<R> &cr, R reach)
 // the fetch latency.  keep(slot) says whether this lane's ray can hit the object at all; the
 // record is fetched only when some lane's can.
 
-// Diagnostic build (-DRTX_COUNT_WALK, tools/walk_count.py): counts group, cluster and object fetches
-// and exact intersections of the bounding-sphere walk, one count per wave and step.
-#ifdef RTX_COUNT_WALK
-static __device__ unsigned long long g_walk[8];
-#define RTX_WALK_COUNT(k) do { if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) atomicAdd(&g_walk[k], 1ull); } while (0)
-#else
-#define RTX_WALK_COUNT(k) do {} while (0)
-#endif
 #define RT_CONSTANT_AS __attribute__((address_space(4)))
 // One value of a table that no kernel writes while it is read (object tables, and the queue
 // lengths the previous launch left): through the constant address space, so that a wave-uniform
@@ -551,71 +537,13 @@ template <typename Rec> RT_DEV Rec load_uniform(const Rec *p)
     __builtin_memcpy(&rec, (const RT_CONSTANT_AS Rec *)p, sizeof(Rec));
     return rec;
 }
-// The same, with every word of the record in a scalar register when this returns.  Left to itself the
-// compiler fetches a record's fields one by one where they are first used, behind the branches of the
-// intersection routine: two or three round trips to the scalar cache per object, each waited for, in
-// waves that are little else than such waits.  This way it is one fetch and one wait.  Measured on the
-// camera and bounce kernels of the small scenes: no difference (RTX_WHOLE_RECORD=1), and with the next
-// record fetched a step ahead (=2) a quarter slower, for the scalar registers it takes; off by default.
-template <typename Rec> RT_DEV Rec load_uniform_whole(const Rec *p)
-{
-    static_assert(sizeof(Rec) % 4 == 0, "records are whole words");
-    constexpr int kWords = (int)(sizeof(Rec) / 4);
-    uint32_t w[kWords];
-    __builtin_memcpy(w, (const RT_CONSTANT_AS Rec *)p, sizeof(Rec));
-#pragma unroll
-    for (int i = 0; i < kWords; ++i) asm volatile("" : "+s"(w[i]));
-    Rec rec;
-    __builtin_memcpy(&rec, w, sizeof(Rec));
-    return rec;
-}
-#ifndef RTX_WHOLE_RECORD
-#define RTX_WHOLE_RECORD 0
-#endif
-#ifdef RTX_LDS_TABLES
-// Experiment (tools build): the five intersection tables are copied into LDS when a workgroup
-// starts (stage_tables) and the brute-force walk reads its records from there, every lane the
-// same address (a broadcast read into vector registers), instead of through the scalar cache
-// into scalar registers.  Only for scenes whose tables fit (no bounding-sphere walk).
-extern __shared__ __attribute__((aligned(16))) unsigned char rtx_lds_tab[];
-template <typename R> struct LdsOffsets { uint32_t sph, pln, cub, cyl, con, end; };
-template <typename R> RT_DEV LdsOffsets<R> lds_offsets(const SceneDev<R> &S)
-{
-    LdsOffsets<R> o;
-    o.sph = 0;
-    o.pln = o.sph + S.n_sph * (uint32_t)sizeof(XformRec<R>);
-    o.cub = o.pln + S.n_pln * (uint32_t)sizeof(PlaneRec<R>);
-    o.cyl = o.cub + S.n_cub * (uint32_t)sizeof(XformRec<R>);
-    o.con = o.cyl + S.n_cyl * (uint32_t)sizeof(CappedRec<R>);
-    o.end = o.con + S.n_con * (uint32_t)sizeof(CappedRec<R>);
-    return o;
-}
-template <typename R> RT_DEV void stage_tables(const SceneDev<R> &S)
-{
-    const LdsOffsets<R> o = lds_offsets(S);
-    const void *src[5] = { S.sph, S.pln, S.cub, S.cyl, S.con };
-    const uint32_t at[6] = { o.sph, o.pln, o.cub, o.cyl, o.con, o.end };
-    for (int t = 0; t < 5; ++t) {
-        const uint4 *from = (const uint4 *)src[t];
-        uint4 *to = (uint4 *)(rtx_lds_tab + at[t]);
-        for (uint32_t i = threadIdx.x; i < (at[t + 1] - at[t]) / 16u; i += blockDim.x) to[i] = from[i];
-    }
-    __syncthreads();
-}
-template <typename Rec> RT_DEV Rec load_lds(uint32_t byte_off, uint32_t i)
-{
-    Rec rec;
-    __builtin_memcpy(&rec, (const __attribute__((address_space(3))) Rec *)(rtx_lds_tab + byte_off) + i, sizeof(Rec));
-    return rec;
-}
-#endif
 // keep.object(slot) says whether this lane's ray can hit the object at all; the record is fetched
 // only when some lane's can.  With Keep::clustered the slots are visited group by group and
 // cluster by cluster, and keep.group(g) / keep.cluster(c) are asked first.
 // group_order: the order in which to meet the table's groups (table-relative indices), or null for table order
 template <typename Rec, typename Keep, typename Body>
 RT_DEV void walk_table(const Rec *recs, uint32_t n, uint32_t slot0, uint32_t cluster0, uint32_t group0, const Keep &keep,
-                       Body &&body, uint32_t lds_off = 0xffffffffu, const uint32_t *group_order = nullptr)
+                       Body &&body, const uint32_t *group_order = nullptr)
 {
     if constexpr (Keep::clustered) {
         // Spheres are fetched four at a time: a walk is a chain of scalar loads, each of which
@@ -627,13 +555,11 @@ RT_DEV void walk_table(const Rec *recs, uint32_t n, uint32_t slot0, uint32_t clu
         for (uint32_t turn = 0; turn < n_grp; ++turn) {
             const uint32_t g_rel = group_order ? ro_load(group_order + turn) : turn;
             const uint32_t g = group0 + g_rel, c0 = g_rel * kCluster;
-            RTX_WALK_COUNT(0);
             const bool kg = keep.group(g);
             if (__ballot(kg) == 0ull) continue;
             const uint32_t c1 = (c0 + kCluster < n_cl) ? c0 + kCluster : n_cl;
             for (uint32_t cb = c0; cb < c1; cb += 4) {
                 bool kc4[4];
-                RTX_WALK_COUNT(1);
                 keep.cluster4(cluster0 + cb, kg, kc4);
                 for (uint32_t j = 0; j < 4; ++j) {
                     const uint32_t c = cb + j;
@@ -642,12 +568,10 @@ RT_DEV void walk_table(const Rec *recs, uint32_t n, uint32_t slot0, uint32_t clu
                     const uint32_t i1 = (i0 + kCluster < n) ? i0 + kCluster : n;
                     for (uint32_t ib = i0; ib < i1; ib += 4) {
                         bool ko4[4];
-                        RTX_WALK_COUNT(2);
                         keep.object4(slot0 + ib, kc4[j], ko4);
                         for (uint32_t e = 0; e < 4; ++e) {
                             const uint32_t i = ib + e;
                             if (i >= i1 || __ballot(ko4[e]) == 0ull) continue;
-                            RTX_WALK_COUNT(3);
                             const Rec rec = load_uniform(recs + i);
                             if (ko4[e]) body(rec, slot0 + i);
                         }
@@ -656,26 +580,10 @@ RT_DEV void walk_table(const Rec *recs, uint32_t n, uint32_t slot0, uint32_t clu
             }
         }
     } else {
-#if RTX_WHOLE_RECORD == 2 && !defined(RTX_LDS_TABLES)
-        if (n == 0u) return;
-        Rec next = load_uniform_whole(recs);
         for (uint32_t i = 0; i < n; ++i) {
-            const Rec rec = next;
-            if (i + 1u < n) next = load_uniform_whole(recs + i + 1u);
-            body(rec, slot0 + i);
-        }
-#else
-        for (uint32_t i = 0; i < n; ++i) {
-#ifdef RTX_LDS_TABLES
-            const Rec rec = lds_off != 0xffffffffu ? load_lds<Rec>(lds_off, i) : load_uniform(recs + i);
-#elif RTX_WHOLE_RECORD == 1
-            const Rec rec = load_uniform_whole(recs + i);
-#else
             const Rec rec = load_uniform(recs + i);
-#endif
             body(rec, slot0 + i);
         }
-#endif
     }
 }
 struct KeepAll {
@@ -708,6 +616,10 @@ struct SphereCull {
     RT_DEV void object4(uint32_t slot, bool outer, bool *out) const { four(bnd + slot, outer, out); }
     RT_DEV void cluster4(uint32_t c, bool outer, bool *out) const { four(cl + c, outer, out); }
     RT_DEV bool group(uint32_t g) const { return !(stop && *stop) && may_hit<R, LINE>(load_uniform(grp + g), cr, reach()); }
+    // one sphere for this lane alone (the index differs from lane to lane)
+    RT_DEV bool lane_group(uint32_t g) const { return may_hit<R, LINE>(grp[g], cr, reach()); }
+    RT_DEV bool lane_cluster(uint32_t c) const { return may_hit<R, LINE>(cl[c], cr, reach()); }
+    RT_DEV bool lane_object(uint32_t slot) const { return may_hit<R, LINE>(bnd[slot], cr, reach()); }
 };
 
 // The same tests for rays that all start at the camera.  Of the 19 operations of may_hit, 10 work
@@ -785,56 +697,6 @@ struct PrimSphereCull {
     RT_DEV bool group(uint32_t g) const { return !dead & may_hit_primary<R, LINE>(head(grp + g), u, reach()); }
 };
 
-// Experiment (tools build, -DRTX_LANE_WALK; measured slower: the five bounce levels of a 4K frame of 10 002
-// objects took 3.1 / 2.3 / 1.05 / 0.67 / 0.38 ms against 1.28 / 0.71 / 0.41 / 0.19 / 0.13 with the walk per wave):
-// the same three-level walk with every lane on its own: for rays that have nothing to do with
-// each other (reflected and refracted rays, and the shadow rays of their hits) the wave-uniform
-// walk above visits the union of what 64 rays need, which is most of the scene, one dependent
-// scalar fetch after another.  Here each lane keeps its own position (next group, the clusters
-// of the group it is in, the objects of the cluster it is in), fetches the sphere its own
-// position names with a vector load, and steps; a lane that reaches an object whose sphere it
-// may hit waits for the others to get that far (or to run out), then the exact intersections run
-// together.  Same tests, same spheres, same result: only the order in which a ray meets the
-// objects changes, and ties between equal t are settled by World index, not by order.
-#ifdef RTX_LANE_WALK
-constexpr bool kLaneWalk = true;
-#else
-constexpr bool kLaneWalk = false;
-#endif
-template <typename R, bool LINE, typename Rec, typename Body>
-RT_DEV void lane_walk_table(const Rec *recs, uint32_t n, uint32_t slot0, uint32_t cluster0, uint32_t group0,
-                            const SphereCull<R, LINE> &keep, Body &&body)
-{
-    if (n == 0u) return;
-    const uint32_t n_cl = (n + kCluster - 1) / kCluster, n_grp = (n_cl + kCluster - 1) / kCluster;
-    uint32_t g = keep.cr.dead ? n_grp : 0u, c = 0u, c_end = 0u, i = 0u, i_end = 0u;
-    for (;;) {
-        bool found = false;
-        uint32_t at = 0u;
-        for (;;) {
-            const bool stopped = keep.stop && *keep.stop;
-            const uint32_t level = stopped ? 3u : i < i_end ? 0u : c < c_end ? 1u : g < n_grp ? 2u : 3u;
-            if (level == 3u) break;
-            const BoundRec<R> *p = level == 0u ? keep.bnd + slot0 + i : level == 1u ? keep.cl + cluster0 + c : keep.grp + group0 + g;
-            const BoundRec<R> b = *p;
-            const bool hit = may_hit<R, LINE>(b, keep.cr, keep.reach());
-            if (level == 0u) {
-                at = i++;
-                if (hit) { found = true; break; }
-            } else if (level == 1u) {
-                if (hit) { i = c * kCluster; i_end = i + kCluster < n ? i + kCluster : n; }
-                ++c;
-            } else {
-                if (hit) { c = g * kCluster; c_end = c + kCluster < n_cl ? c + kCluster : n_cl; }
-                ++g;
-            }
-        }
-        if (!found) break;
-        const Rec rec = recs[at];
-        body(rec, slot0 + at);
-    }
-}
-
 // The walk for a wave that holds ONE ray (the deep recursion levels of a scene with thousands of
 // objects hold a few thousand rays for a chip of 65 000 lanes): the ray is the same in every lane
 // and the 64 lanes test 64 spheres of a level at once -- every group of a table, then the 16
@@ -845,7 +707,11 @@ RT_DEV void lane_walk_table(const Rec *recs, uint32_t n, uint32_t slot0, uint32_
 // them); what a finished batch found shortens the reach of the next (wave_best).
 // Same tests, same spheres, same exact intersections as the other walks; the order in which
 // objects are met differs, and ties between equal t are settled by World index, not by order.
-enum : int { WALK_WAVE = 0, WALK_LANE = 1, WALK_WIDE = 2 };
+// WALK_WAVE, WALK_WIDE: bounding spheres fetched from memory; WALK_LANE, WALK_TREE, WALK_TREE_WIDE: the packed
+// hierarchy in LDS walked per lane, per wave, and by a whole wave for one ray
+enum : int { WALK_WAVE = 0, WALK_LANE = 1, WALK_WIDE = 2, WALK_TREE = 3, WALK_TREE_WIDE = 4 };
+constexpr bool walk_in_lds(int walk) { return walk == WALK_LANE || walk == WALK_TREE || walk == WALK_TREE_WIDE; }
+constexpr bool walk_is_wide(int walk) { return walk == WALK_WIDE || walk == WALK_TREE_WIDE; }
 template <typename T> RT_DEV T wave_min(T v)
 {
     for (int off = 32; off > 0; off >>= 1) {
@@ -868,9 +734,9 @@ RT_DEV uint32_t pop_four(unsigned long long &mask, uint32_t pos[4])
     }
     return count;
 }
-template <typename R, bool LINE, typename Rec, typename Body>
+template <typename R, typename Keep, typename Rec, typename Body>
 RT_DEV void wide_walk_table(const Rec *recs, uint32_t n, uint32_t slot0, uint32_t cluster0, uint32_t group0,
-                            const SphereCull<R, LINE> &keep, const R *lane_best, R *wave_best, Body &&body)
+                            const Keep &keep, const R *lane_best, R *wave_best, Body &&body)
 {
     static_assert(kCluster == 16, "a quarter of the wave per cluster");
     if (n == 0u) return;
@@ -881,14 +747,14 @@ RT_DEV void wide_walk_table(const Rec *recs, uint32_t n, uint32_t slot0, uint32_
     auto mine = [&](const uint32_t v[4]) { return quarter == 0u ? v[0] : quarter == 1u ? v[1] : quarter == 2u ? v[2] : v[3]; };
     for (uint32_t g0 = 0; g0 < n_grp; g0 += 64u) {
         bool hit_g = false;
-        if (g0 + lane < n_grp) hit_g = may_hit<R, LINE>(keep.grp[group0 + g0 + lane], keep.cr, keep.reach());
+        if (g0 + lane < n_grp) hit_g = keep.lane_group(group0 + g0 + lane);
         unsigned long long groups = __ballot(hit_g);
         while (groups != 0ull) {
             uint32_t gpos[4];
             const uint32_t n_g = pop_four(groups, gpos);
             const uint32_t c = (g0 + mine(gpos)) * kCluster + member;
             bool hit_c = false;
-            if (quarter < n_g && c < n_cl) hit_c = may_hit<R, LINE>(keep.cl[cluster0 + c], keep.cr, keep.reach());
+            if (quarter < n_g && c < n_cl) hit_c = keep.lane_cluster(cluster0 + c);
             unsigned long long clusters = __ballot(hit_c);
             while (clusters != 0ull) {
                 uint32_t cpos[4], cidx[4];
@@ -896,7 +762,7 @@ RT_DEV void wide_walk_table(const Rec *recs, uint32_t n, uint32_t slot0, uint32_
                 for (int j = 0; j < 4; ++j) cidx[j] = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)cpos[j]);  // the cluster lane cpos[j] tested
                 const uint32_t i = mine(cidx) * kCluster + member;
                 bool hit_o = false;
-                if (quarter < n_c && i < n) hit_o = may_hit<R, LINE>(keep.bnd[slot0 + i], keep.cr, keep.reach());
+                if (quarter < n_c && i < n) hit_o = keep.lane_object(slot0 + i);
                 if (hit_o) {
                     const Rec rec = recs[i];
                     body(rec, slot0 + i);
@@ -904,6 +770,192 @@ RT_DEV void wide_walk_table(const Rec *recs, uint32_t n, uint32_t slot0, uint32_
                 if (__ballot(hit_o) != 0ull) {
                     if (keep.stop && __ballot(*keep.stop) != 0ull) return;
                     if (lane_best) *wave_best = wave_min(*lane_best);
+                }
+            }
+        }
+    }
+}
+
+// The walk for secondary rays that have nothing to do with each other (reflected and refracted rays
+// of a scene of thousands of objects, and the shadow rays of their hits): every lane walks the
+// hierarchy for its own ray.  The wave-uniform walk visits the union of what 64 such rays need --
+// most of the scene's groups, hundreds of clusters -- one dependent scalar fetch (a microsecond
+// under load) after another.  Here the hierarchy is the packed copy a workgroup keeps in LDS
+// (QuantNode: 8 bytes a sphere, stage_lane_tree), a lane reads the sphere its own position names at
+// LDS latency, and only what the packed spheres let through is fetched from memory and intersected
+// exactly -- per lane, a different object in every lane, with the expressions of the other walks.
+// The packed spheres hold the stored ones (rounded outwards on the host), the tests are may_hit's
+// in single precision on a ray moved to where it enters the sphere around all bounded objects, and a
+// ray's own allowance covers what the exact test's rounding grows to when the true origin is far
+// away (as the allowance of the exact path does): the objects that reach an exact intersection
+// include all that can be hit, so hits, colours and counters are those of the other walks.
+#define RT_LDS_AS __attribute__((address_space(3)))
+template <typename R>
+struct LaneTreeCull {
+    static constexpr bool clustered = true;
+    const RT_LDS_AS unsigned long long *nodes;  // the packed hierarchy in LDS: objects by slot, then clusters, then groups
+    uint32_t cl0, grp0;            // node index of the first cluster and of the first group sphere
+    float base[3], step;
+    CullRay<float> cr;
+    float extra_r;                 // added to every radius: sqrt of the exact test's allowance for this ray
+    R dlen, shift;                 // |direction| and how far along it cr.o lies from the ray's origin
+    const R *best;
+    R limit;
+    R limit_closed;                // the same for spheres and cubes (containers_behind; elsewhere = limit)
+    const bool *stop;
+    RT_DEV float reach() const
+    {
+        const R t = best ? Num<R>::min_(*best, limit) : limit;
+        const float r = (float)(t * dlen - shift);
+        return __builtin_fmaf(__builtin_fabsf(r), 4e-7f, r) + extra_r;  // rounded up; inf stays inf
+    }
+    RT_DEV bool test(uint32_t node, float rch) const
+    {
+        const unsigned long long q = nodes[node];
+        const uint32_t lo = (uint32_t)q, hi = (uint32_t)(q >> 32);
+        BoundRec<float> b;
+        b.c[0] = __builtin_fmaf((float)(lo & 0xffffu), step, base[0]);
+        b.c[1] = __builtin_fmaf((float)(lo >> 16), step, base[1]);
+        b.c[2] = __builtin_fmaf((float)(hi & 0xffffu), step, base[2]);
+        const uint32_t qr = hi >> 16;
+        b.r = qr == 0xffffu ? Num<float>::inf : __builtin_fmaf((float)qr, step, extra_r);
+        return may_hit<float, false>(b, cr, rch);
+    }
+    RT_DEV bool stopped() const { return stop && *stop; }
+    // for the walk of a whole wave (walk_table): the same sphere for every lane, its own answer for each
+    RT_DEV bool group(uint32_t g) const { return !stopped() && test(grp0 + g, reach()); }
+    RT_DEV void four(uint32_t first, bool outer, bool *out) const
+    {
+        const bool live = outer && !stopped();
+        const float rch = reach();
+        for (uint32_t j = 0; j < 4u; ++j) out[j] = live & test(first + j, rch);
+    }
+    RT_DEV void cluster4(uint32_t c, bool outer, bool *out) const { four(cl0 + c, outer, out); }
+    RT_DEV void object4(uint32_t slot, bool outer, bool *out) const { four(slot, outer, out); }
+    // for the walk of one ray by a whole wave (wide_walk_table)
+    RT_DEV bool lane_group(uint32_t g) const { return test(grp0 + g, reach()); }
+    RT_DEV bool lane_cluster(uint32_t c) const { return test(cl0 + c, reach()); }
+    RT_DEV bool lane_object(uint32_t slot) const { return test(slot, reach()); }
+};
+template <typename R>
+RT_DEV LaneTreeCull<R> lane_tree_cull(const SceneDev<R> &S, V3<R> o, V3<R> d, const R *best, R limit, const bool *stop)
+{
+    LaneTreeCull<R> k;
+    k.nodes = (const RT_LDS_AS unsigned long long *)(uintptr_t)S.q_lds;
+    k.cl0 = S.n_bnd_total;
+    k.grp0 = S.n_bnd_total + S.n_cl_total;
+    k.base[0] = S.q_base[0]; k.base[1] = S.q_base[1]; k.base[2] = S.q_base[2];
+    k.step = S.q_step;
+    k.best = best;
+    k.limit = limit;
+    k.limit_closed = limit;
+    k.stop = stop;
+    // the ray in the scalar type of the kernel: unit direction, and the point where its line enters the
+    // sphere around all bounded objects when it starts outside (nothing bounded lies before that point)
+    const R d2 = dot3(d, d);
+    k.dlen = Num<R>::sqrt_(d2);
+    const R inv = R(1) / k.dlen;
+    const V3<R> u = { d.x * inv, d.y * inv, d.z * inv };
+    const R oo = dot3(o, o);
+    k.cr.dead = !(d2 == d2) || !(oo == oo);  // a NaN in the ray: every t of every shape is NaN, nothing is hit
+    const V3<R> m = { S.world_c[0] - o.x, S.world_c[1] - o.y, S.world_c[2] - o.z };
+    const R m2 = dot3(m, m);
+    V3<R> from = o;
+    k.shift = R(0);
+    if (m2 > S.world_r * S.world_r) {  // never true of a NaN or of an infinite radius
+        const R tc = dot3(m, u);
+        k.cr.dead = k.cr.dead || tc < R(0);  // the whole sphere lies behind the origin
+        const R s = tc - S.world_r;
+        if (Num<R>::abs_(s) < Num<R>::big) {
+            from = { o.x + u.x * s, o.y + u.y * s, o.z + u.z * s };
+            k.shift = s;
+        }
+    }
+    k.cr.o = { (float)from.x, (float)from.y, (float)from.z };
+    k.cr.u = { (float)u.x, (float)u.y, (float)u.z };
+    k.cr.dlen = 1.0f;
+    k.cr.shift = 0.0f;
+    // The exact intersection is evaluated from the true origin, and its rounding grows with the squared
+    // distance of an object from there (the allowance of may_hit in the exact path: cull_slack * m2):
+    // the same allowance here, as an addition to the radius, with the farthest bounded object's distance.
+    k.extra_r = 0.0f;
+    if constexpr (Num<R>::exact) {
+        const R far_ = Num<R>::sqrt_(m2) + S.world_r;
+        const float e = (float)(far_ * R(1.0e-6));  // sqrt(cull_slack) * distance
+        k.extra_r = e == e ? e * 1.0001f : Num<float>::inf;
+    }
+    return k;
+}
+// The cull state a walk uses for the table of one shape.
+template <typename Keep> RT_DEV const Keep &keep_for_shape(const Keep &k, uint32_t) { return k; }
+template <typename R> RT_DEV LaneTreeCull<R> keep_for_shape(const LaneTreeCull<R> &k, uint32_t shape)
+{
+    LaneTreeCull<R> out = k;
+    if (shape == SH_SPHERE || shape == SH_CUBE) out.limit = k.limit_closed;
+    return out;
+}
+// Every thread of the workgroup: the packed hierarchy from memory into LDS (ends with a barrier).
+template <typename R> RT_DEV void stage_lane_tree(const SceneDev<R> &S, RT_LDS_AS unsigned long long *lds, uint32_t n_threads)
+{
+    // two nodes per lane and step (the table is padded to an even count and 16-byte aligned)
+    const uint4 *from = reinterpret_cast<const uint4 *>(S.q_nodes);
+    RT_LDS_AS uint4 *to = (RT_LDS_AS uint4 *)lds;
+    const uint32_t n2 = (S.q_n + 1u) / 2u;
+#pragma unroll 4
+    for (uint32_t i = threadIdx.x; i < n2; i += n_threads) {
+        const uint4 v = from[i];
+        to[i].x = v.x; to[i].y = v.y; to[i].z = v.z; to[i].w = v.w;
+    }
+    __syncthreads();
+}
+// One shape table for one ray per lane.  keep.test() is asked for the groups of the table (all lanes
+// together: the same group for every lane, its own answer for each), then per lane for the 16 clusters
+// of each group its ray may hit, the 16 members of each such cluster, and body(rec, slot) runs for the
+// members that are left, one at a time, with the record fetched by the lane itself.
+template <typename R, typename Rec, typename Body>
+RT_DEV void lane_tree_walk_table(const Rec *recs, uint32_t n, uint32_t slot0, uint32_t cluster0, uint32_t group0,
+                                 const LaneTreeCull<R> &keep, Body &&body)
+{
+    static_assert(kCluster == 16, "sixteen answers per mask");
+    if (n == 0u || keep.cr.dead) return;
+    const uint32_t n_cl = (n + kCluster - 1) / kCluster, n_grp = (n_cl + kCluster - 1) / kCluster;
+    for (uint32_t g0 = 0; g0 < n_grp; g0 += 64u) {
+        if (keep.stopped()) return;
+        unsigned long long groups = 0ull;
+        {
+            const float rch = keep.reach();
+            const uint32_t g1 = g0 + 64u < n_grp ? g0 + 64u : n_grp;
+            for (uint32_t g = g0; g < g1; ++g)
+                if (keep.test(keep.grp0 + group0 + g, rch)) groups |= 1ull << (g - g0);
+        }
+        while (groups != 0ull) {
+            const uint32_t g = g0 + (uint32_t)__builtin_ctzll(groups);
+            groups &= groups - 1ull;
+            uint32_t clusters = 0u;
+            {
+                const float rch = keep.reach();
+                const uint32_t c0 = g * kCluster;
+#pragma unroll
+                for (uint32_t j = 0; j < kCluster; ++j)
+                    if (c0 + j < n_cl && keep.test(keep.cl0 + cluster0 + c0 + j, rch)) clusters |= 1u << j;
+            }
+            while (clusters != 0u) {
+                const uint32_t c = g * kCluster + (uint32_t)__builtin_ctz(clusters);
+                clusters &= clusters - 1u;
+                uint32_t members = 0u;
+                {
+                    const float rch = keep.reach();
+                    const uint32_t i0 = c * kCluster;
+#pragma unroll
+                    for (uint32_t j = 0; j < kCluster; ++j)
+                        if (i0 + j < n && keep.test(slot0 + i0 + j, rch)) members |= 1u << j;
+                }
+                while (members != 0u) {
+                    const uint32_t i = c * kCluster + (uint32_t)__builtin_ctz(members);
+                    members &= members - 1u;
+                    if (keep.stopped()) return;
+                    const Rec rec = recs[i];
+                    body(rec, slot0 + i);
                 }
             }
         }
@@ -1148,19 +1200,20 @@ RT_DEV void walk_scene_tables(const SceneDev<R> &S, V3<R> ro, V3<R> rd, Bounded 
     if constexpr (CHAIN) walk_chained(S, ro, rd, per);
 }
 
-// `table(recs, n, slot0, cluster0, group0, body)`: one table, walked wave by wave, lane by lane, or by
-// the whole wave for one ray (lane_best, wave_best: see wide_walk_table)
+// `table(recs, n, slot0, cluster0, group0, body)`: one table, walked wave by wave (keep: SphereCull or
+// KeepAll), lane by lane (LaneTreeCull), or by the whole wave for one ray (SphereCull; lane_best, wave_best:
+// see wide_walk_table)
 template <typename R, bool CHAIN, int WALK = WALK_WAVE, typename Keep, typename Per>
 RT_DEV void walk_scene(const SceneDev<R> &S, V3<R> ro, V3<R> rd, const Keep &keep, Per &&per, const R *lane_best = nullptr,
                        R *wave_best = nullptr)
 {
-    if constexpr (WALK != WALK_WAVE && Keep::clustered) {
+    if constexpr ((WALK == WALK_LANE || walk_is_wide(WALK)) && Keep::clustered) {
         uint32_t base = 0;
         auto lane_walk_table = [&](auto recs, uint32_t n, uint32_t slot0, uint32_t cluster0, uint32_t group0, const Keep &k, auto &&body) {
-            if constexpr (WALK == WALK_WIDE) wide_walk_table(recs, n, slot0, cluster0, group0, k, lane_best, wave_best, body);
-            else rtx::lane_walk_table(recs, n, slot0, cluster0, group0, k, body);
+            if constexpr (walk_is_wide(WALK)) wide_walk_table<R>(recs, n, slot0, cluster0, group0, k, lane_best, wave_best, body);
+            else lane_tree_walk_table(recs, n, slot0, cluster0, group0, k, body);
         };
-        lane_walk_table(S.sph, S.n_sph, base, S.cl_off[SH_SPHERE], S.grp_off[SH_SPHERE], keep, [&](const XformRec<R> &rec, uint32_t slot) {
+        lane_walk_table(S.sph, S.n_sph, base, S.cl_off[SH_SPHERE], S.grp_off[SH_SPHERE], keep_for_shape(keep, SH_SPHERE), [&](const XformRec<R> &rec, uint32_t slot) {
             const V3<R> o = xform_point(rec.m, ro);
             const V3<R> d = xform_vector(rec.m, rd);
             per(slot, [&](auto &&emit) { isect_sphere(o, d, sphere_c(o), emit); });
@@ -1172,7 +1225,7 @@ RT_DEV void walk_scene(const SceneDev<R> &S, V3<R> ro, V3<R> rd, const Keep &kee
             per(slot, [&](auto &&emit) { isect_plane(-oy, dy, emit); });
         });
         base += S.n_pln;
-        lane_walk_table(S.cub, S.n_cub, base, S.cl_off[SH_CUBE], S.grp_off[SH_CUBE], keep, [&](const XformRec<R> &rec, uint32_t slot) {
+        lane_walk_table(S.cub, S.n_cub, base, S.cl_off[SH_CUBE], S.grp_off[SH_CUBE], keep_for_shape(keep, SH_CUBE), [&](const XformRec<R> &rec, uint32_t slot) {
             const V3<R> o = xform_point(rec.m, ro);
             const V3<R> d = xform_vector(rec.m, rd);
             const V3<R> lo = { R(-1) - o.x, R(-1) - o.y, R(-1) - o.z };
@@ -1192,21 +1245,13 @@ RT_DEV void walk_scene(const SceneDev<R> &S, V3<R> ro, V3<R> rd, const Keep &kee
             per(slot, [&](auto &&emit) { isect_cone(o, twice(o), cone_c(o), d, rec.ymin, rec.ymax, rec.closed != 0, emit); });
         });
         if constexpr (CHAIN) walk_chained(S, ro, rd, per);
-        return;
+    } else {
+        walk_scene_tables<R, CHAIN, false>(S, ro, rd, [&](auto recs, uint32_t n, uint32_t slot0, uint32_t shape, auto &&body) {
+            walk_table(recs, n, slot0, S.cl_off[shape], S.grp_off[shape], keep_for_shape(keep, shape), body);
+        }, [&](auto recs, uint32_t n, uint32_t slot0, uint32_t shape, auto &&body) {
+            walk_table(recs, n, slot0, 0u, 0u, KeepAll(), body);
+        }, per);
     }
-#ifdef RTX_LDS_TABLES
-    const LdsOffsets<R> lo_ = lds_offsets(S);
-    constexpr bool kLds = !Keep::clustered;
-    const uint32_t lds_at[5] = { kLds ? lo_.sph : 0xffffffffu, kLds ? lo_.pln : 0xffffffffu, kLds ? lo_.cub : 0xffffffffu,
-                                 kLds ? lo_.cyl : 0xffffffffu, kLds ? lo_.con : 0xffffffffu };
-#else
-    const uint32_t lds_at[5] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu };
-#endif
-    walk_scene_tables<R, CHAIN, false>(S, ro, rd, [&](auto recs, uint32_t n, uint32_t slot0, uint32_t shape, auto &&body) {
-        walk_table(recs, n, slot0, S.cl_off[shape], S.grp_off[shape], keep, body, lds_at[shape]);
-    }, [&](auto recs, uint32_t n, uint32_t slot0, uint32_t shape, auto &&body) {
-        walk_table(recs, n, slot0, 0u, 0u, KeepAll(), body, lds_at[shape]);
-    }, per);
 }
 
 // The same walk for primary rays: they all start at the camera, so the object-space origin
@@ -1267,7 +1312,7 @@ RT_DEV void walk_scene_primary(const SceneDev<R> &S, const PrimScene<R> &P, V3<R
 {
     const uint32_t *const order = Keep::clustered ? P.grp_order : nullptr;
     walk_primary_tables<R, CHAIN>(S, P, ro, rd, [&](auto recs, uint32_t n, uint32_t slot0, uint32_t shape, auto &&body) {
-        walk_table(recs, n, slot0, S.cl_off[shape], S.grp_off[shape], keep, body, 0xffffffffu, order ? order + S.grp_off[shape] : nullptr);
+        walk_table(recs, n, slot0, S.cl_off[shape], S.grp_off[shape], keep, body, order ? order + S.grp_off[shape] : nullptr);
     }, [&](auto &&run) { run(); }, per);
 }
 // The camera rays of a whole wave (beam_walk_table); every lane calls this, `valid`: it holds a ray.
@@ -1430,6 +1475,22 @@ struct Hit {
 
 constexpr uint32_t kNone = 0xffffffffu;
 
+// An object with an odd number of intersections behind the ray's origin is in `containers` when the
+// hit is reached; `last_neg` (its largest negative t) places it in that list.  Keeps the last two.
+template <typename R, typename Before>
+RT_DEV void note_open_container(Hit<R> &h, uint32_t slot, R last_neg, Before &&before)
+{
+    // later in the sorted list = larger t, or equal t and later in World.objects
+    const bool after1 = last_neg > h.top1_t || (last_neg == h.top1_t && (h.top1 == kNone || before(h.top1, slot)));
+    if (after1) {
+        h.top2 = h.top1; h.top2_t = h.top1_t;
+        h.top1 = slot; h.top1_t = last_neg;
+    } else {
+        const bool after2 = last_neg > h.top2_t || (last_neg == h.top2_t && (h.top2 == kNone || before(h.top2, slot)));
+        if (after2) { h.top2 = slot; h.top2_t = last_neg; }
+    }
+}
+
 template <typename R, bool TRACK, bool COLD_LDS = false, bool WIDE = false, typename Walk>
 RT_DEV Hit<R> closest_hit_with(const SceneDev<R> &S, Walk &&walk)
 {
@@ -1466,17 +1527,7 @@ RT_DEV Hit<R> closest_hit_with(const SceneDev<R> &S, Walk &&walk)
             if (any_pos && best <= h.t) {
                 if (best < h.t || h.slot == kNone || before(slot, h.slot)) { h.t = best; h.slot = slot; h.hit_open = open; }
             }
-            if (open) {
-                // later in the sorted list = larger t, or equal t and later in World.objects
-                const bool after1 = last_neg > h.top1_t || (last_neg == h.top1_t && (h.top1 == kNone || before(h.top1, slot)));
-                if (after1) {
-                    h.top2 = h.top1; h.top2_t = h.top1_t;
-                    h.top1 = slot; h.top1_t = last_neg;
-                } else {
-                    const bool after2 = last_neg > h.top2_t || (last_neg == h.top2_t && (h.top2 == kNone || before(h.top2, slot)));
-                    if (after2) { h.top2 = slot; h.top2_t = last_neg; }
-                }
-            }
+            if (open) note_open_container(h, slot, last_neg, before);
         }
     });
     if (h.slot != kNone) {
@@ -1508,7 +1559,20 @@ RT_DEV Hit<R> closest_hit_with(const SceneDev<R> &S, Walk &&walk)
 template <typename R, bool TRACK, bool CULL, bool CHAIN, int WALK = WALK_WAVE, bool COLD_LDS = false>
 RT_DEV Hit<R> closest_hit(const SceneDev<R> &S, V3<R> ro, V3<R> rd, R t_limit)
 {
-    if constexpr (CULL && WALK == WALK_WIDE) {
+    if constexpr (CULL && WALK == WALK_TREE_WIDE) {
+        static_assert(!TRACK, "the packed hierarchy is walked ahead of the origin only; containers come from containers_behind");
+        return closest_hit_with<R, TRACK, COLD_LDS, true>(S, [&](const R *best, auto &&per) {
+            R wave_best = Num<R>::inf;
+            const LaneTreeCull<R> keep = lane_tree_cull<R>(S, ro, rd, &wave_best, t_limit, nullptr);
+            walk_scene<R, CHAIN, WALK_TREE_WIDE>(S, ro, rd, keep, per, best, &wave_best);
+        });
+    } else if constexpr (CULL && walk_in_lds(WALK)) {
+        static_assert(!TRACK, "the packed hierarchy is walked ahead of the origin only; containers come from containers_behind");
+        return closest_hit_with<R, TRACK, COLD_LDS>(S, [&](const R *best, auto &&per) {
+            const LaneTreeCull<R> keep = lane_tree_cull<R>(S, ro, rd, best, t_limit, nullptr);
+            walk_scene<R, CHAIN, WALK == WALK_LANE ? WALK_LANE : WALK_WAVE>(S, ro, rd, keep, per);
+        });
+    } else if constexpr (CULL && WALK == WALK_WIDE) {
         return closest_hit_with<R, TRACK, COLD_LDS, true>(S, [&](const R *best, auto &&per) {
             R wave_best = Num<R>::inf;  // the closest hit any lane has found so far (refreshed after every batch of exact tests)
             const SphereCull<R, TRACK> keep = { S.bnd, S.cl, S.grp, cull_ray<R, TRACK>(S, ro, rd), &wave_best, t_limit, nullptr };
@@ -1545,6 +1609,51 @@ RT_DEV Hit<R> closest_hit_primary_beam(const SceneDev<R> &S, const PrimScene<R> 
     return closest_hit_with<R, false>(S, [&](const R *best, auto &&per) { walk_scene_primary_beam<R, CHAIN>(S, P, ro, rd, valid, best, per); });
 }
 
+// The container bookkeeping of prepare_computations (world.rs:253-285) as a walk of its own, for a ray
+// whose closest hit `h` is known.  n1 and n2 are read by refracted_color and schlick alone, both
+// behind `transparency != 0`, so in a scene of thousands of objects of which a few are glass almost
+// no ray needs them -- while finding them in the same pass as the hit means looking at every
+// intersection on the whole line (the objects behind the origin as well), which rules out everything
+// that makes the walk over the sphere hierarchy fast (nothing behind the origin, nothing beyond the
+// closest hit so far, whole waves at a time).  What precedes the hit in the reference's sorted list are
+// the intersections with t < 0: exactly what the ray sent backwards from the same origin meets.  This
+// walk therefore culls with that reversed ray (unlimited reach) and intersects the objects it is left
+// with exactly as the forward walk does (same ray, same t), keeping the negative t only.
+template <typename R, bool CHAIN, int WALK = WALK_WAVE>
+RT_DEV void containers_behind(const SceneDev<R> &S, V3<R> ro, V3<R> rd, Hit<R> &h)
+{
+    auto before = [&](uint32_t slot, uint32_t other) { return ro_load(S.slot_obj + slot) < ro_load(S.slot_obj + other); };
+    h.hit_open = false;
+    h.top1 = h.top2 = kNone;
+    h.top1_t = h.top2_t = -Num<R>::inf;
+    const V3<R> back = { -rd.x, -rd.y, -rd.z };
+    auto per = [&](uint32_t slot, auto &&run) {
+        R last_neg = -Num<R>::inf;
+        uint32_t n_neg = 0;
+        run([&](R t, bool ok = true) {
+            const bool neg = ok && t < R(0);
+            n_neg += neg ? 1u : 0u;
+            last_neg = Num<R>::max_(last_neg, neg ? t : -Num<R>::inf);
+        });
+        bool open = false;
+        if (n_neg & 1u) open = (ro_load(&S.cold[ro_load(S.slot_obj + slot)].flags) & OF_CONTAINER) != 0;
+        if (slot == h.slot) h.hit_open = open;
+        if (open) note_open_container(h, slot, last_neg, before);
+    };
+    if constexpr (walk_in_lds(WALK)) {  // (a wave that holds one ray walks it as a wave of 64 equal rays)
+        // A sphere's two roots and a cube's two slab distances have an odd number of negative values only when
+        // they straddle zero, which is the origin inside the shape: of those two tables the objects whose
+        // bounding sphere holds the origin are enough (reach 0).  The other shapes can be crossed an odd number
+        // of times behind the origin (open ends, the caps' own tests) and are looked at all the way back.
+        LaneTreeCull<R> keep = lane_tree_cull<R>(S, ro, back, nullptr, Num<R>::inf, nullptr);
+        keep.limit_closed = R(0);
+        walk_scene<R, CHAIN, WALK == WALK_LANE ? WALK_LANE : WALK_WAVE>(S, ro, rd, keep, per);
+    } else {
+        const SphereCull<R, false> keep = { S.bnd, S.cl, S.grp, cull_ray<R, false>(S, ro, back), nullptr, Num<R>::inf, nullptr };
+        walk_scene<R, CHAIN, WALK_WAVE>(S, ro, rd, keep, per);
+    }
+}
+
 // src/scenes/world.rs:146-158.  shadowed iff the closest hit (t >= 0) lies before the light
 // and its object casts a shadow.  When every object casts, any hit with 0 <= t < distance
 // decides it, so the walk needs no closest-hit bookkeeping.
@@ -1560,7 +1669,11 @@ RT_DEV bool is_shadowed(const SceneDev<R> &S, V3<R> p, V3<R> dir, R distance)
                 if (ok && t >= R(0) && t < distance) shadowed = true;
             });
         };
-        if constexpr (CULL) {
+        if constexpr (CULL && walk_in_lds(WALK)) {
+            const LaneTreeCull<R> keep = lane_tree_cull<R>(S, p, dir, nullptr, distance, &shadowed);
+            walk_scene<R, CHAIN, WALK == WALK_TREE ? WALK_WAVE : WALK>(S, p, dir, keep, per);
+            if constexpr (WALK == WALK_TREE_WIDE) shadowed = __ballot(shadowed) != 0ull;  // any lane's object
+        } else if constexpr (CULL) {
             const SphereCull<R, false> keep = { S.bnd, S.cl, S.grp, cull_ray<R, false>(S, p, dir), nullptr, distance, &shadowed };
             walk_scene<R, CHAIN, WALK>(S, p, dir, keep, per);
             if constexpr (WALK == WALK_WIDE) shadowed = __ballot(shadowed) != 0ull;  // any lane's object
@@ -1689,26 +1802,6 @@ struct Node {
     R refract_factor;     // transparency [* (1 - schlick)]
 };
 
-#ifdef RTX_PHASE_CLOCK
-// Diagnostic build: cycles per phase of a color_at node, summed over waves (tools/phase_clock.py)
-static __device__ unsigned long long g_phase[16];
-// per-wave sums in LDS; a kernel clears them when it starts and adds them to g_phase when it ends
-__device__ __forceinline__ unsigned long long *phase_lds()
-{
-    __shared__ unsigned long long acc[4][16];
-    return acc[threadIdx.x >> 6];
-}
-__device__ __forceinline__ bool phase_leader() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == (uint32_t)(__ffsll((long long)__ballot(1)) - 1); }
-#define RTX_PHASE_MARK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (phase_leader()) phase_lds()[k] += now_ - phase_t_; phase_t_ = __builtin_readcyclecounter(); } while (0)
-#define RTX_PHASE_BEGIN() unsigned long long phase_t_ = __builtin_readcyclecounter()
-#define RTX_PHASE_INIT() do { if ((threadIdx.x & 63u) < 16u) phase_lds()[threadIdx.x & 63u] = 0ull; } while (0)
-#define RTX_PHASE_FLUSH() do { if ((threadIdx.x & 63u) < 16u && phase_lds()[threadIdx.x & 63u]) atomicAdd(&g_phase[threadIdx.x & 63u], phase_lds()[threadIdx.x & 63u]); } while (0)
-#else
-#define RTX_PHASE_MARK(k) do {} while (0)
-#define RTX_PHASE_BEGIN() do {} while (0)
-#define RTX_PHASE_INIT() do {} while (0)
-#define RTX_PHASE_FLUSH() do {} while (0)
-#endif
 // `children(nd)` is called for every ray that hits something, as soon as its child rays are
 // known and before the shadow ray and the lighting are evaluated: a kernel that queues the
 // children there has their registers free during the second walk.  The call sits in divergent
@@ -1722,18 +1815,32 @@ template <typename R, uint32_t SF, bool PRIMARY = false, int WALK = WALK_WAVE, b
 RT_DEV Node<R> shade_node(const SceneDev<R> &S, V3<R> ro, V3<R> rd, uint32_t remaining, const Hit<R> &h,
                           Children &&children = Children());
 
-template <typename R, uint32_t SF, bool PRIMARY = false, int WALK = WALK_WAVE, bool COLD_LDS = false, typename Children = NoChildrenHook>
+// Scenes with transparency and the sphere hierarchy find the closest hit first and do the container
+// bookkeeping afterwards, for the rays that need it (containers_behind); the others do both in one pass.
+constexpr bool deferred_containers(uint32_t sf) { return (sf & SF_TRANSPARENT) != 0 && (sf & SF_CULL) != 0; }
+// ALWAYS: n1 and n2 of every hit (the probe kernel reports them); otherwise only where they are read:
+// the hit object is transparent and the ray may still spawn a refraction ray
+template <typename R, uint32_t SF, bool COLD_LDS, bool ALWAYS = false, int WALK = WALK_WAVE>
+RT_DEV void containers_if_needed(const SceneDev<R> &S, V3<R> ro, V3<R> rd, uint32_t remaining, Hit<R> &h)
+{
+    if constexpr (deferred_containers(SF)) {
+        bool needed = h.slot != kNone;
+        if constexpr (!ALWAYS) needed = needed && remaining != 0u && ColdTable<R, COLD_LDS>::base(S)[h.slot != kNone ? h.obj : 0u].transparency != R(0);
+        if (needed) containers_behind<R, (SF & SF_CHAIN) != 0, walk_in_lds(WALK) ? WALK : WALK_WAVE>(S, ro, rd, h);
+    }
+}
+template <typename R, uint32_t SF, bool PRIMARY = false, int WALK = WALK_WAVE, bool COLD_LDS = false, bool ALL_CONTAINERS = false,
+          typename Children = NoChildrenHook>
 RT_DEV Node<R> trace_node(const SceneDev<R> &S, const PrimScene<R> *P, V3<R> ro, V3<R> rd, uint32_t remaining,
                           Children &&children = Children())
 {
-    constexpr bool TRACK = (SF & SF_TRANSPARENT) != 0;
+    constexpr bool TRACK = (SF & SF_TRANSPARENT) != 0 && !deferred_containers(SF);
     Hit<R> h;
     constexpr bool CULL = (SF & SF_CULL) != 0;
     constexpr bool CHAIN = (SF & SF_CHAIN) != 0;
-    RTX_PHASE_BEGIN();
     if constexpr (PRIMARY) h = closest_hit_primary<R, TRACK, CULL, CHAIN>(S, *P, ro, rd);
     else h = closest_hit<R, TRACK, CULL, CHAIN, WALK, COLD_LDS>(S, ro, rd, Num<R>::inf);
-    RTX_PHASE_MARK(PRIMARY ? 8 : 0);
+    containers_if_needed<R, SF, COLD_LDS, ALL_CONTAINERS, WALK>(S, ro, rd, remaining, h);
     return shade_node<R, SF, PRIMARY, WALK, COLD_LDS>(S, ro, rd, remaining, h, children);
 }
 
@@ -1753,7 +1860,6 @@ RT_DEV Node<R> shade_prepare(const SceneDev<R> &S, V3<R> ro, V3<R> rd, uint32_t 
     Node<R> nd;
     nd.has_reflect = nd.has_refract = false;
     nd.lighting = { R(0), R(0), R(0) };
-    RTX_PHASE_BEGIN();
     nd.hit = h.slot != kNone;
     nd.obj = h.obj;
     nd.t = h.t;
@@ -1858,9 +1964,7 @@ RT_DEV Node<R> shade_prepare(const SceneDev<R> &S, V3<R> ro, V3<R> rd, uint32_t 
             nd.refract_factor = transparency * (R(1) - reflectance);
         }
     }
-    RTX_PHASE_MARK(PRIMARY ? 9 : 1);
     children(nd);
-    RTX_PHASE_MARK(PRIMARY ? 10 : 2);
 
     // shade_hit, world.rs:121-123.  is_shadowed (world.rs:146-150) and lighting (lights.rs:49)
     // both normalise light.position - over_point; the vector is formed once here.
@@ -1876,7 +1980,6 @@ RT_DEV void shade_finish(const SceneDev<R> &S, V3<R> rd, Node<R> &nd, const Shad
     const V3<R> eyev = { -rd.x, -rd.y, -rd.z };
     const V3<R> over = nd.over_point, normalv = nd.normalv, lightv = query.lightv;
     nd.shadowed = shadowed;
-    RTX_PHASE_BEGIN();
     // lighting, lights.rs:43-78, evaluated at over_point
     V3<R> clr = { cold.color[0], cold.color[1], cold.color[2] };
     if constexpr ((SF & SF_PATTERN) != 0) {
@@ -1908,7 +2011,6 @@ RT_DEV void shade_finish(const SceneDev<R> &S, V3<R> rd, Node<R> &nd, const Shad
                    (result.z + diffuse.z) + specular.z };
     }
     nd.lighting = result;
-    RTX_PHASE_MARK(PRIMARY ? 12 : 4);
 }
 
 template <typename R, uint32_t SF, bool PRIMARY, int WALK, bool COLD_LDS, typename Children>
@@ -1917,9 +2019,7 @@ RT_DEV Node<R> shade_node(const SceneDev<R> &S, V3<R> ro, V3<R> rd, uint32_t rem
     ShadowQuery<R> query;
     Node<R> nd = shade_prepare<R, SF, PRIMARY, COLD_LDS>(S, ro, rd, remaining, h, query, children);
     if (!nd.hit) return nd;
-    RTX_PHASE_BEGIN();
     const bool shadowed = is_shadowed<R, SF, WALK, COLD_LDS>(S, nd.over_point, query.lightv, query.ldist);
-    RTX_PHASE_MARK(PRIMARY ? 11 : 3);
     shade_finish<R, SF, PRIMARY, COLD_LDS>(S, rd, nd, query, shadowed);
     return nd;
 }

@@ -136,11 +136,10 @@ RT_DEV void primary_ray(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> ro, V
     };
     // camera rays of a scene with the sphere hierarchy: the wave finds its closest hits together, and
     // then whether they are shadowed (shadow rays all end at the light)
-    constexpr bool kBeam = CAM && (SF & SF_CULL) != 0 && (SF & SF_TRANSPARENT) == 0 && kBeamWalk;
+    constexpr bool kBeam = CAM && (SF & SF_CULL) != 0 && kBeamWalk;
     if constexpr (kBeam) {
-        RTX_PHASE_BEGIN();
-        const Hit<R> h = closest_hit_primary_beam<R, (SF & SF_CHAIN) != 0>(S, P, ro, rd, valid);
-        RTX_PHASE_MARK(8);
+        Hit<R> h = closest_hit_primary_beam<R, (SF & SF_CHAIN) != 0>(S, P, ro, rd, valid);
+        if (valid) containers_if_needed<R, SF, false>(S, ro, rd, remaining, h);
         ShadowQuery<R> query = { { R(0), R(0), R(0) }, R(0) };
         nd.over_point = { R(0), R(0), R(0) };
         if (valid) nd = shade_prepare<R, SF, CAM, false>(S, ro, rd, remaining, h, query, children);
@@ -148,7 +147,6 @@ RT_DEV void primary_ray(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> ro, V
         bool shadowed = false;
         if constexpr ((SF & SF_ALL_CAST) != 0) shadowed = is_shadowed_beam<R, SF>(S, P, nd.over_point, query.lightv, query.ldist, asks);
         else if (asks) shadowed = is_shadowed<R, SF, WALK_WAVE, false>(S, nd.over_point, query.lightv, query.ldist);
-        RTX_PHASE_MARK(11);
         if (asks) shade_finish<R, SF, CAM, false>(S, rd, nd, query, shadowed);
     }
     if (valid) {
@@ -193,9 +191,6 @@ k_primary_camera(CameraDev<R> cam, SceneDev<R> S, PrimScene<R> P, uint32_t local
                  uint32_t remaining, void *__restrict__ fb, QueueDev<R> out_q, StatShard *__restrict__ stats, RowMap map,
                  uint32_t format)
 {
-#ifdef RTX_LDS_TABLES
-    if constexpr ((SF & SF_CULL) == 0) stage_tables<R>(S);
-#endif
     // a two-dimensional grid: row of pieces = blockIdx.y (a division by pieces_per_row otherwise, thirty
     // instructions in front of everything else in waves of three hundred)
     const uint32_t piece_row = blockIdx.y;
@@ -211,7 +206,6 @@ k_primary_camera(CameraDev<R> cam, SceneDev<R> S, PrimScene<R> P, uint32_t local
     }
     const bool valid = row < n_rows && x < cam.hsize;
     V3<R> ro = { R(0), R(0), R(0) }, rd = ro;
-    RTX_PHASE_INIT();
     if (valid) {
         // plain row ranges come with local0 = their first image row and never read the map
         uint32_t image_row = local0 + row;
@@ -220,7 +214,6 @@ k_primary_camera(CameraDev<R> cam, SceneDev<R> S, PrimScene<R> P, uint32_t local
         ray_for_pixel(cam, x, image_row, ro, rd);
     }
     primary_ray<R, SF, true, OUT8>(S, P, ro, rd, row * cam.hsize + x, valid, remaining, fb, format, out_q, stats, block_id);
-    RTX_PHASE_FLUSH();
 }
 
 // Rays from a caller-supplied array (World::color_at batches), one per thread.
@@ -229,9 +222,6 @@ __global__ void __launch_bounds__(kRayBlock<R>)
 k_primary_rays(SceneDev<R> S, const double *__restrict__ rays, uint32_t n, uint32_t remaining, R *__restrict__ fb,
                QueueDev<R> out_q, StatShard *__restrict__ stats)
 {
-#ifdef RTX_LDS_TABLES
-    if constexpr ((SF & SF_CULL) == 0) stage_tables<R>(S);
-#endif
     const PrimScene<R> none = {};
     const uint32_t k = blockIdx.x * kRayBlock<R> + threadIdx.x;
     const bool valid = k < n;
@@ -348,17 +338,6 @@ constexpr uint32_t sf_case(uint32_t sf)
     }
 #endif
 
-// dynamic LDS a kernel is launched with: the intersection tables in the LDS-table experiment
-template <typename R> inline uint32_t table_lds_bytes(const SceneDev<R> &S)
-{
-#ifdef RTX_LDS_TABLES
-    if (S.flags & SF_CULL) return 0u;
-    return (uint32_t)((S.n_sph + S.n_cub) * sizeof(XformRec<R>) + S.n_pln * sizeof(PlaneRec<R>) + (S.n_cyl + S.n_con) * sizeof(CappedRec<R>) + 16u);
-#else
-    (void)S;
-    return 0u;
-#endif
-}
 template <typename R>
 hipError_t Launch<R>::primary_camera(uint32_t sf, hipStream_t stream, const CameraDev<R> &cam, const SceneDev<R> &scene,
                                      const PrimScene<R> &prim, const RowMap &map, uint32_t local0, uint32_t n_rows,
@@ -371,7 +350,7 @@ hipError_t Launch<R>::primary_camera(uint32_t sf, hipStream_t stream, const Came
     const bool banded = map.n_parts != 1u;
     const uint32_t first = banded ? local0 : map.first + local0;  // what the kernel adds its row to
 #define RTX_LAUNCH_CAM(SFV, OUT8, BANDED)                                                                            \
-    hipLaunchKernelGGL((k_primary_camera<R, SFV | SF_PATTERN, OUT8, BANDED>), grid, dim3(kCamBlock<R>), table_lds_bytes(scene), \
+    hipLaunchKernelGGL((k_primary_camera<R, SFV | SF_PATTERN, OUT8, BANDED>), grid, dim3(kCamBlock<R>), 0, \
                        stream, cam, scene, prim, first, n_rows, remaining, fb, out_q, stats, map, format)
 #define RTX_CALL(SFV)                                                                                                \
     if constexpr (((SFV) & (SF_REFLECTIVE | SF_TRANSPARENT)) == 0) {                                               \
@@ -393,7 +372,7 @@ hipError_t Launch<R>::primary_rays(uint32_t sf, hipStream_t stream, const SceneD
 {
     const uint32_t grid = (n + kRayBlock<R> - 1) / kRayBlock<R>;
 #define RTX_CALL(SFV)                                                                                           \
-    hipLaunchKernelGGL((k_primary_rays<R, SFV | SF_PATTERN>), dim3(grid), dim3(kRayBlock<R>), table_lds_bytes(scene), stream, scene, rays, n, \
+    hipLaunchKernelGGL((k_primary_rays<R, SFV | SF_PATTERN>), dim3(grid), dim3(kRayBlock<R>), 0, stream, scene, rays, n, \
                        remaining, fb, out_q, stats)
     RTX_SF_SWITCH(sf, RTX_CALL)
 #undef RTX_CALL

@@ -32,6 +32,7 @@ template <typename R> constexpr uint32_t kRayBlock = sizeof(R) == 8 ? RTX_RAY_BL
 #endif
 template <typename R> constexpr uint32_t bounce_block(uint32_t sf)
 {
+    if (sf & SF_LANE_TREE) return kLaneTreeBlock;
     return sizeof(R) == 8 ? ((sf & 16u /* SF_CULL */) ? RTX_RAY_BLOCK_F64 : RTX_BOUNCE_BLOCK_F64_SMALL_SCENE) : RTX_RAY_BLOCK_F32;
 }
 // Threads per workgroup of the camera kernel.  Its waves share nothing.  In f64 one wave per
@@ -102,11 +103,11 @@ struct Launch {
 template <typename R>
 hipError_t launch_bounce(uint32_t sf, hipStream_t stream, const SceneDev<R> &scene, const QueueDev<R> &in_q,
                          const QueueDev<R> &out_q, uint32_t remaining, uint32_t level, R *fb, StatShard *stats,
-                         uint32_t resident_blocks, uint32_t longest = 0);
+                         uint32_t resident_blocks, uint32_t longest = 0, int tree_walk = 3);
 extern template hipError_t launch_bounce<double>(uint32_t, hipStream_t, const SceneDev<double> &, const QueueDev<double> &,
-                                                 const QueueDev<double> &, uint32_t, uint32_t, double *, StatShard *, uint32_t, uint32_t);
+                                                 const QueueDev<double> &, uint32_t, uint32_t, double *, StatShard *, uint32_t, uint32_t, int);
 extern template hipError_t launch_bounce<float>(uint32_t, hipStream_t, const SceneDev<float> &, const QueueDev<float> &,
-                                                const QueueDev<float> &, uint32_t, uint32_t, float *, StatShard *, uint32_t, uint32_t);
+                                                const QueueDev<float> &, uint32_t, uint32_t, float *, StatShard *, uint32_t, uint32_t, int);
 
 // Size of the file-scope device array behind rtx_render_device_noalloc (scratch.hip), and its
 // device address on the current device.

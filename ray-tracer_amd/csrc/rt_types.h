@@ -24,6 +24,7 @@ enum : uint32_t {
     SF_PATTERN = 8u,      // some object carries a non-solid pattern
     SF_CULL = 16u,        // enough bounded objects that testing their bounding spheres first pays
     SF_CHAIN = 32u,       // some object sits inside a Group
+    SF_LANE_TREE = 64u,   // the packed copy of the sphere hierarchy fits a workgroup's LDS (QuantNode, below)
 };
 
 // ---- intersection tables -------------------------------------------------------------
@@ -83,6 +84,20 @@ struct alignas(sizeof(R) * 4) BoundRec {
 #define RTX_CLUSTER 16
 #endif
 constexpr uint32_t kCluster = RTX_CLUSTER;
+// The same hierarchy once more, 8 bytes a sphere: centre and radius in units of `step` from `base`
+// (SceneDev::q_*), the centre rounded to the nearest unit and the radius rounded up by more than the
+// centre can have moved, so that the packed sphere holds the stored one.  r = 0xffff: unbounded.
+// Small enough (objects, clusters and groups of a scene of ten thousand objects: 86 KB) to sit in the
+// LDS of a workgroup, where every lane can walk it for its own ray at LDS latency (lane_tree_walk).
+struct QuantNode {
+    uint16_t c[3];
+    uint16_t r;
+};
+constexpr uint32_t kLaneTreeMaxNodes = 11776;  // 92 KB of the 160 KB a workgroup can have
+#ifndef RTX_LANE_TREE_BLOCK
+#define RTX_LANE_TREE_BLOCK 1024
+#endif
+constexpr uint32_t kLaneTreeBlock = RTX_LANE_TREE_BLOCK;  // threads of a workgroup that holds the packed hierarchy (one per CU)
 
 // ---- primary-ray tables -----------------------------------------------------------------
 // Every primary ray starts at the camera, so each object's object-space ray origin and the
@@ -198,6 +213,11 @@ struct SceneDev {
     R light_int[3];
     R world_c[3];   // sphere around every object that has a finite bounding sphere (bounding-sphere
     R world_r;      // tests only; +inf: none)
+    // SF_LANE_TREE: the packed hierarchy, nodes in the order bnd | cl | grp (same indices as those tables)
+    const QuantNode *q_nodes;
+    uint32_t q_n;
+    uint32_t q_lds;  // where the running workgroup keeps its copy in LDS (set by the kernel that stages it)
+    float q_base[3], q_step;
 };
 
 template <typename R>

@@ -128,7 +128,10 @@ struct rtx_context {
     uint32_t cull_min_objects = 16;  // scenes with at least this many bounded objects get the bounding-sphere tests
     uint32_t blocks_per_cu = 8;
     uint32_t bounce_blocks = 7680;   // workgroups of one bounce launch (set from the device's size at creation)
-    uint32_t bounce_blocks_cull = 0xffffffffu;  // the same for scenes with bounding-sphere tests: one per piece the queue can hold
+    uint32_t bounce_blocks_cull = 65536u;  // the same for scenes with bounding-sphere tests: one per piece the queue can hold, up to this many
+    uint32_t bounce_blocks_lane = 512u;    // and for the kernel that keeps the packed hierarchy in LDS (one resident workgroup per CU)
+    bool lane_tree = true;                 // scenes uploaded from now on may use that kernel
+    int tree_walk = 1;                     // how it walks long levels: 1 every lane for itself, 3 a wave at a time
     void *scratch = nullptr;         // this device's copy of the file-scope array of scratch.hip
     size_t scratch_bytes = 0;
     uint32_t *overflow_host = nullptr;  // pinned word the kernels set when a ray queue overflows
@@ -618,9 +621,70 @@ void fill_tables(const rtx_scene_desc *d, const std::vector<uint8_t> &container,
     }
 }
 
+// The packed copy of the sphere hierarchy (QuantNode): the spheres of `t` (objects by slot, clusters,
+// groups, padding included) on a grid of 65 536 steps per axis over the box of their centres.  A packed
+// sphere holds the stored one: its radius is rounded up and widened by what the centre can have moved
+// (half a step per axis), by what single-precision arithmetic on the unpacked numbers loses, and by what
+// a ray loses when its double-precision origin and direction are rounded to single precision.  Empty
+// (nodes.size() == 0) when the scene has no hierarchy or it does not fit a workgroup's LDS.
+struct QuantTree {
+    std::vector<QuantNode> nodes;
+    float base[3] = { 0.f, 0.f, 0.f }, step = 1.f;
+};
+QuantTree quantize_tree(const Tables<double> &t)
+{
+    QuantTree q;
+    const size_t total = t.bnd.size() + t.cl.size() + t.grp.size();
+    if (t.grp.empty() || total > kLaneTreeMaxNodes) return q;
+    double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
+    bool any = false;
+    for (const auto *v : { &t.bnd, &t.cl, &t.grp })
+        for (const BoundRec<double> &b : *v)
+            if (std::isfinite(b.r)) {
+                any = true;
+                for (int a = 0; a < 3; ++a) {
+                    lo[a] = std::min(lo[a], b.c[a]);
+                    hi[a] = std::max(hi[a], b.c[a]);
+                }
+            }
+    if (!any) return q;
+    double extent = 0.0, maxabs = 0.0;
+    for (int a = 0; a < 3; ++a) {
+        extent = std::max(extent, hi[a] - lo[a]);
+        maxabs = std::max(maxabs, std::max(std::fabs(lo[a]), std::fabs(hi[a])));
+    }
+    const double world = maxabs + extent + (std::isfinite(t.world_r) ? 2.0 * t.world_r : 0.0);
+    const double step = std::max(extent / 65535.0, std::max(world * 1e-7, 1e-30));
+    if (!std::isfinite(step) || !std::isfinite(world) || world > 1e30) return q;
+    q.step = (float)step;
+    const double stepf = (double)q.step;
+    for (int a = 0; a < 3; ++a) q.base[a] = (float)lo[a];
+    // the centre moves by half a step per axis (sqrt(3)/2 of a step) plus the rounding of base and of the
+    // unpacking; rays rounded to single precision move by a few units in the last place of the coordinates
+    const double margin = 0.9 * stepf + 64.0 * 1.2e-7 * world;
+    q.nodes.reserve(total);
+    for (const auto *v : { &t.bnd, &t.cl, &t.grp })
+        for (const BoundRec<double> &b : *v) {
+            QuantNode n = { { 0, 0, 0 }, 0xffffu };
+            if (std::isfinite(b.r)) {
+                bool inside = true;
+                for (int a = 0; a < 3; ++a) {
+                    const double g = std::nearbyint((b.c[a] - (double)q.base[a]) / stepf);
+                    if (!(g >= 0.0 && g <= 65535.0)) inside = false;
+                    else n.c[a] = (uint16_t)g;
+                }
+                const double r = std::ceil((b.r * (1.0 + 2e-3) + margin) / stepf) + 1.0;
+                if (inside && r < 65535.0) n.r = (uint16_t)r;
+                else n.c[0] = n.c[1] = n.c[2] = 0;
+            }
+            q.nodes.push_back(n);
+        }
+    return q;
+}
+
 // One device allocation per scene and precision holding all tables back to back.
 template <typename R>
-int upload_tables(const Tables<R> &t, uint32_t sf, const rtx_scene_desc *d, void **blob, SceneDev<R> *dev)
+int upload_tables(const Tables<R> &t, const QuantTree &qt, uint32_t sf, const rtx_scene_desc *d, void **blob, SceneDev<R> *dev)
 {
     auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t b_sph = pad(t.sph.size() * sizeof(XformRec<R>)), b_pln = pad(t.pln.size() * sizeof(PlaneRec<R>)),
@@ -629,8 +693,8 @@ int upload_tables(const Tables<R> &t, uint32_t sf, const rtx_scene_desc *d, void
                  b_flags = pad(t.slot_flags.size() * sizeof(uint32_t)),
                  b_cold = pad(t.cold.size() * sizeof(ColdRec<R>)), b_bnd = pad(t.bnd.size() * sizeof(BoundRec<R>)),
                  b_cl = pad(t.cl.size() * sizeof(BoundRec<R>)), b_grp = pad(t.grp.size() * sizeof(BoundRec<R>)),
-                 b_chn = pad(t.chn.size() * sizeof(ChainRec<R>));
-    const size_t total = b_sph + b_pln + b_cub + b_cyl + b_con + b_slot + b_flags + b_cold + b_bnd + b_cl + b_grp + b_chn + 256;
+                 b_chn = pad(t.chn.size() * sizeof(ChainRec<R>)), b_q = pad(qt.nodes.size() * sizeof(QuantNode));
+    const size_t total = b_sph + b_pln + b_cub + b_cyl + b_con + b_slot + b_flags + b_cold + b_bnd + b_cl + b_grp + b_chn + b_q + 256;
     std::vector<char> host(total, 0);
     size_t off = 0;
     auto put = [&](const void *src, size_t bytes, size_t padded) {
@@ -651,6 +715,7 @@ int upload_tables(const Tables<R> &t, uint32_t sf, const rtx_scene_desc *d, void
     const size_t o_cl = put(t.cl.data(), t.cl.size() * sizeof(BoundRec<R>), b_cl);
     const size_t o_grp = put(t.grp.data(), t.grp.size() * sizeof(BoundRec<R>), b_grp);
     const size_t o_chn = put(t.chn.data(), t.chn.size() * sizeof(ChainRec<R>), b_chn);
+    const size_t o_q = put(qt.nodes.data(), qt.nodes.size() * sizeof(QuantNode), b_q);
     HIP_TRY(hipMalloc(blob, total));
     HIP_TRY(hipMemcpy(*blob, host.data(), total, hipMemcpyHostToDevice));
     char *base = (char *)*blob;
@@ -667,6 +732,11 @@ int upload_tables(const Tables<R> &t, uint32_t sf, const rtx_scene_desc *d, void
     dev->cl = (const BoundRec<R> *)(base + o_cl);
     dev->grp = (const BoundRec<R> *)(base + o_grp);
     dev->chn = (const ChainRec<R> *)(base + o_chn);
+    dev->q_nodes = qt.nodes.empty() ? nullptr : (const QuantNode *)(base + o_q);
+    dev->q_n = (uint32_t)qt.nodes.size();
+    dev->q_lds = 0u;
+    for (int k = 0; k < 3; ++k) dev->q_base[k] = qt.base[k];
+    dev->q_step = qt.step;
     dev->n_chn = (uint32_t)t.chn.size();
     dev->n_grp_total = (uint32_t)t.grp.size();
     dev->n_bnd_total = (uint32_t)t.bnd.size();
@@ -765,7 +835,10 @@ void size_queues(uint32_t sf, uint32_t levels, uint32_t hsize, uint64_t units, F
         p->cap_sub[L] = cap;
         uint64_t &tot = (L & 1) ? p->odd_entries : p->even_entries;
         tot = std::max(tot, cap * n_sub);
-        cap = ((cap + bounce_block<R>(sf) - 1) / bounce_block<R>(sf)) * bounce_block<R>(sf) * g;
+        // (an output sub-queue is fed by one block per block index of the input; a block holds at most
+        // bounce_block rays, and no more than its whole sub-queue)
+        const uint64_t piece = bounce_block<R>(sf);
+        cap = ((cap + piece - 1) / piece) * std::min<uint64_t>(piece, cap) * g;
     }
     p->bytes = (size_t)((p->odd_entries + p->even_entries) * 8 * sizeof(R));
 }
@@ -1115,7 +1188,9 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Workspace &ws, hipEv
             // its length leave at once; measured 6.9 against 7.4 ms on the 10k-object frame), the
             // others as many workgroups as the chip holds at once.
             HIP_TRY(launch_bounce<R>(scene->sf, stream, S, queue_at(L), queue_at(L + 1), max_depth - L, L, fb, ws.shards,
-                                     (scene->sf & SF_CULL) ? ctx->bounce_blocks_cull : ctx->bounce_blocks));
+                                     (scene->sf & SF_LANE_TREE) ? ctx->bounce_blocks_lane
+                                                                : (scene->sf & SF_CULL) ? ctx->bounce_blocks_cull : ctx->bounce_blocks,
+                                     0u, ctx->tree_walk));
             ++launches;
         }
         done += cam ? units * W : units;
@@ -1393,10 +1468,17 @@ int rtx_context_create(int device_id, rtx_context **out)
     // (4K glass frame: 2.04 ms with 8 per CU, 1.93 with 16, 1.84 with 30, 1.81-1.88 with 50-100; one per
     // piece, 2.57).  Handing the pieces out by ticket instead was slower than this fixed split.
     ctx->bounce_blocks = (uint32_t)ctx->cu_count * 30u;
+    ctx->bounce_blocks_lane = (uint32_t)ctx->cu_count;
     if (const char *e = std::getenv("RTX_BOUNCE_BLOCKS")) {
         int v = std::atoi(e);
         if (v >= 1) ctx->bounce_blocks = (uint32_t)v;
     }
+    if (const char *e = std::getenv("RTX_BOUNCE_BLOCKS_LANE")) {
+        int v = std::atoi(e);
+        if (v >= 1) ctx->bounce_blocks_lane = (uint32_t)v;
+    }
+    if (const char *e = std::getenv("RTX_LANE_TREE")) ctx->lane_tree = std::atoi(e) != 0;
+    if (const char *e = std::getenv("RTX_TREE_WALK")) ctx->tree_walk = std::atoi(e) == 1 ? 1 : 3;
     if (const char *e = std::getenv("RTX_BOUNCE_BLOCKS_CULL")) {
         int v = std::atoi(e);
         if (v >= 1) ctx->bounce_blocks_cull = (uint32_t)v;
@@ -1561,13 +1643,17 @@ int rtx_scene_upload(rtx_context *ctx, const rtx_scene_desc *d, rtx_scene **out)
     uint32_t n_bounded = 0;
     const std::vector<Bound> bounds = scene_bounds(d, &n_bounded);
     if (n_bounded >= ctx->cull_min_objects) sf |= SF_CULL;
-    s->sf = sf;
     Tables<double> t64;
     Tables<float> t32;
     fill_tables<double>(d, container, bounds, (sf & SF_CULL) != 0, t64);
     fill_tables<float>(d, container, bounds, (sf & SF_CULL) != 0, t32);
-    int rc = upload_tables<double>(t64, sf, d, &s->blob64, &s->dev64);
-    if (!rc) rc = upload_tables<float>(t32, sf, d, &s->blob32, &s->dev32);
+    // secondary rays of a scene whose packed hierarchy fits a workgroup's LDS are walked lane by lane
+    QuantTree qt;
+    if ((sf & SF_CULL) && ctx->lane_tree) qt = quantize_tree(t64);
+    if (!qt.nodes.empty()) sf |= SF_LANE_TREE;
+    s->sf = sf;
+    int rc = upload_tables<double>(t64, qt, sf, d, &s->blob64, &s->dev64);
+    if (!rc) rc = upload_tables<float>(t32, qt, sf, d, &s->blob32, &s->dev32);
     if (rc) {
         rtx_scene_destroy(s.release());
         return rc;

@@ -96,11 +96,13 @@ def glass_scene(api, hsize=3840, vsize=2160, n_lights=1):
     return w, cam
 
 
-def random_scene(api, n_objects=10000, hsize=3840, vsize=2160, seed=0xC0FFEE, light=(-30.0, 60.0, -40.0), no_shadow_every=0):
+def random_scene(api, n_objects=10000, hsize=3840, vsize=2160, seed=0xC0FFEE, light=(-30.0, 60.0, -40.0), no_shadow_every=0,
+                 glass_every=0):
     """S4: n random spheres / cubes / closed cylinders plus a checker floor and a striped back
     wall.  Scales stay >= 0.3 so every transform has |det| >= 1e-5 (the reference panics
     below that, src/matrices/matrix4.rs:100-107).  Variants for tests: another light position;
-    every no_shadow_every-th object casting no shadow."""
+    every no_shadow_every-th object casting no shadow; every glass_every-th object made of glass
+    (transparency 0.9, reflective 0.9, refractive index 1.5, as spheres::glass_sphere has it)."""
     rng = SplitMix64(seed)
     w = api.world()
     for index in range(n_objects):
@@ -123,6 +125,8 @@ def random_scene(api, n_objects=10000, hsize=3840, vsize=2160, seed=0xC0FFEE, li
             o.set_reflective(0.3)
         if no_shadow_every and index % no_shadow_every == 0:
             o.set_casts_shadow(False)
+        if glass_every and index % glass_every == 1:
+            o.set_transparency(0.9).set_reflective(0.9).set_refractive_index(1.5)
         w.add_object(o)
     w.add_object(api.plane().set_pattern(CHECKER3D, (0.85, 0.85, 0.85), (0.2, 0.2, 0.25))
                  .set_pattern_transform(api.m_scaling(2.0, 2.0, 2.0)).set_specular(0.1))
@@ -169,10 +173,16 @@ def grouped_scene(api, hsize=160, vsize=90, nested=True):
     return w, cam
 
 
+def random_scene_with_glass(api, n_objects=10000, hsize=3840, vsize=2160, **kw):
+    """The random scene with every 400th object made of glass (25 of 10 000)."""
+    return random_scene(api, n_objects=n_objects, hsize=hsize, vsize=vsize, glass_every=400, **kw)
+
+
 SCENES = {
     "default": default_scene,
     "spheres_on_plane": spheres_on_plane,
     "glass": glass_scene,
     "random": random_scene,
+    "random_glass": random_scene_with_glass,
     "grouped": grouped_scene,
 }

@@ -69,6 +69,62 @@ def test_ten_thousand_objects_at_full_size(orc, rta):
     assert np.abs(band - img[1070:1100]).max() <= 1e-12
 
 
+def test_ten_thousand_objects_some_of_glass(orc, rta):
+    """The same cloud with every 400th object made of glass (25 of 10 002): the scene then carries the
+    container bookkeeping of prepare_computations (src/scenes/world.rs:253-285), which the kernels do
+    as a walk of its own for the rays that hit glass.  Colours and counters of 1 500 camera rays and
+    1 500 rays aimed at the glass objects against the oracle's color_at, n1 / n2 and the rest of the
+    intermediate results of 500 of them bit for bit, and the 4K frame at the sampled pixels."""
+    from ray_tracer_amd import scenes
+    W, H = 3840, 2160
+    gw, gcam = scenes.random_scene(rta.api, hsize=W, vsize=H, glass_every=400)
+    ow, ocam = scenes.random_scene(orc.api, hsize=W, vsize=H, glass_every=400)
+    flat = rta.flatten(gw)
+    glass = np.flatnonzero(flat["transparency"] != 0.0)
+    assert len(glass) == 25 and len(gw) == 10002
+    rng = np.random.default_rng(77)
+    xs, ys = rng.integers(0, W, 1500), rng.integers(0, H, 1500)
+    cam_rays = _camera_rays(orc, ocam, xs, ys)
+    # rays towards (and, from a point inside, out of) the glass objects: centre = inverse^-1 * origin
+    centres = np.array([np.linalg.inv(flat["inverse"].reshape(-1, 4, 4)[i])[:3, 3] for i in glass])
+    pick = centres[rng.integers(0, len(centres), 1500)]
+    o = pick + rng.normal(0.0, 1.0, (1500, 3)) * np.where(rng.uniform(size=(1500, 1)) < 0.3, 0.15, 6.0)
+    target = pick + rng.normal(0.0, 0.2, (1500, 3))
+    d = target - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([cam_rays, np.concatenate([o, d], axis=1)])
+    g_cnt, o_cnt = [0, 0], [0, 0]
+    got = rta.color_at(gw, rays, 5, counters=g_cnt)
+    want = orc.color_at(ow, rays, 5, counters=o_cnt)
+    assert np.abs(got - want).max() <= TOL
+    assert g_cnt == o_cnt, "ray counters differ: GPU %s oracle %s" % (g_cnt, o_cnt)
+
+    from test_gpu_parity import oracle_probe
+    sub = rays[1500:][::3][:500]
+    probes = rta.probe(gw, sub)
+    hits_on_glass = 0
+    for g, w_, r in zip(probes, oracle_probe(orc, ow, sub), sub):
+        if w_ is None:
+            assert g["object"] == -1
+            continue
+        t, obj, c = w_
+        assert g["object"] == obj and g["t"] == t, "hit differs for ray %s" % (r,)
+        assert g["n1"] == c.n1 and g["n2"] == c.n2, "n1/n2 differ for ray %s: %s %s, oracle %s %s" % (r, g["n1"], g["n2"], c.n1, c.n2)
+        assert np.array_equal(g["point"], c.point[:]) and np.array_equal(g["normalv"], c.normalv[:])
+        hits_on_glass += int(obj in glass)
+    assert hits_on_glass > 100
+
+    st = {}
+    img = rta.render_rows(gcam, gw, stats=st)
+    assert np.abs(img[ys, xs] - want[:1500]).max() <= TOL
+    assert st["rays_per_level"][0] == W * H and st["rays_per_level"][5] > 0
+    # the fast path: at least 99.9 % of the sampled pixels within one 8-bit level
+    img32 = rta.render_rows(gcam, gw, precision=rta.F32)
+    q_got = orc.quantize_u8(img32[ys, xs].astype(np.float64)).astype(np.int32)
+    q_want = orc.quantize_u8(want[:1500]).astype(np.int32)
+    assert np.all(np.abs(q_got - q_want) <= 1, axis=1).mean() >= 0.995
+
+
 def test_default_world_4k_on_the_f32_path(orc, rta):
     """BASELINE config 2 in f32: after the reference's 8-bit conversion (src/scenes/canvas.rs:84-86)
     at least 99.9 % of the pixels are within one level of the f64 oracle, on 40 000 sampled
