@@ -48,7 +48,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--scene", default="glass", choices=["default", "spheres_on_plane", "glass", "random"])
+    ap.add_argument("--scene", default="glass", choices=["default", "spheres_on_plane", "glass", "random", "random_glass"])
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--depth", type=int, default=5)
@@ -70,7 +70,7 @@ def parse_args():
 def build_scene(rta, name, width, height, objects, n_lights=1):
     from ray_tracer_amd import scenes
     kw = dict(hsize=width, vsize=height)
-    if name == "random":
+    if name in ("random", "random_glass"):
         kw["n_objects"] = objects
     if n_lights != 1:
         kw["n_lights"] = n_lights
@@ -100,7 +100,7 @@ def cpu_baseline(scene_name, width, height, depth, objects, target_cpu_seconds):
     orc = entry.load_oracle()
     from ray_tracer_amd import scenes
     kw = dict(hsize=width, vsize=height)
-    if scene_name == "random":
+    if scene_name in ("random", "random_glass"):
         kw["n_objects"] = objects
     world, cam = scenes.SCENES[scene_name](orc.api, **kw)
     threads = host_threads()
@@ -613,6 +613,7 @@ def extra_scenes(rta, ctx, args):
     # lights[0] only, so its four lights cost what one does)
     cases = [("default", "f64", {}), ("default", "f32", {}), ("spheres_on_plane", "f64", {}), ("glass", "f64", {}), ("glass", "f32", {}),
              ("random", "f64", {"objects": 10000}), ("random", "f32", {"objects": 10000}),
+             ("random_glass", "f64", {"objects": 10000}), ("random_glass", "f32", {"objects": 10000}),
              ("glass", "f64", {"width": 7680, "height": 4320, "n_lights": 4, "key": "glass_4lights_7680x4320_f64"})]
     never = (1 << 64) - 1
 

@@ -41,7 +41,15 @@ extern "C" {
 enum { RTX_SPHERE = 0, RTX_PLANE = 1, RTX_CUBE = 2, RTX_CYLINDER = 3, RTX_CONE = 4 };
 /* src/surfaces/patterns.rs:13-20 (enum PatternType) */
 enum { RTX_SOLID = 0, RTX_STRIPE = 1, RTX_GRADIENT = 2, RTX_RING = 3, RTX_CHECKER3D = 4, RTX_TEST = 5 };
-/* precision of the render arithmetic */
+/* Precision of the render arithmetic.  RTX_F64 is the reference's own arithmetic (see "the same result" above).
+ * RTX_F32 is a fast path without a bit contract: after the reference's 8-bit conversion (src/scenes/canvas.rs:84-86)
+ * at least 99.9 % of a frame's pixels are within one level of the f64 result.  One exception: objects inside
+ * transformed Groups.  The reference shades such an object with a copy whose transform is rebuilt from merged
+ * transformation lists (src/shapes/traits.rs:35-44) and is not the transform its ray was intersected with, so
+ * over_point can lie inside the object and what the rays that start there hit is decided by the last bits of the
+ * hit point, which f32 does not have; measured on randomised worlds with such groups: 95-100 % of a frame's
+ * pixels, 99 % on average (tests/test_gpu_parity.py, test_f32_fast_path_on_grouped_objects).  Untransformed
+ * groups and the plain objects of the same frames keep the 99.9 %. */
 enum { RTX_F64 = 0, RTX_F32 = 1 };
 
 typedef struct rtx_context rtx_context;
@@ -162,6 +170,11 @@ int rtx_context_queue_bytes(rtx_context *ctx, size_t *bytes);
  * tests only skip objects the reference's intersection routines would miss (no counterpart in
  * the reference, which tests every object, src/scenes/world.rs:98-107). */
 int rtx_context_set_cull_threshold(rtx_context *ctx, uint32_t min_bounded_objects);
+/* Scenes uploaded afterwards with bounding-sphere tests may (enabled != 0, the default) have their secondary
+ * rays walk a packed copy of the sphere hierarchy kept in LDS, every lane for its own ray, when that copy fits
+ * (about 11 000 objects); otherwise a wave walks the spheres in memory for its 64 rays together.  Results do
+ * not depend on it (tests/test_beam_walk.py).  No counterpart in the reference. */
+int rtx_context_set_lane_walk(rtx_context *ctx, int enabled);
 
 /* Replaces the World a render borrows (src/scenes/world.rs:6-9): validates, repacks and
  * copies the scene to the device.  Fails (as the reference panics, world.rs:123,147) when

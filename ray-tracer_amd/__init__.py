@@ -118,6 +118,7 @@ rtx_context_set_workspace_limit = _bind("rtx_context_set_workspace_limit", C.c_i
 rtx_context_set_measured_queues = _bind("rtx_context_set_measured_queues", C.c_int, [_vp, C.c_size_t])
 rtx_context_queue_bytes = _bind("rtx_context_queue_bytes", C.c_int, [_vp, C.POINTER(C.c_size_t)])
 rtx_context_set_cull_threshold = _bind("rtx_context_set_cull_threshold", C.c_int, [_vp, C.c_uint32])
+rtx_context_set_lane_walk = _bind("rtx_context_set_lane_walk", C.c_int, [_vp, C.c_int])
 rtx_scene_upload = _bind("rtx_scene_upload", C.c_int, [_vp, C.POINTER(SceneDesc), C.POINTER(_vp)])
 rtx_scene_destroy = _bind("rtx_scene_destroy", None, [_vp])
 rtx_scene_features = _bind("rtx_scene_features", C.c_int, [_vp, C.POINTER(C.c_uint32)])
@@ -163,7 +164,7 @@ rtx_device_info = _bind("rtx_device_info", C.c_int, [_vp, C.c_char_p, C.c_size_t
 # every symbol include/rtx.h declares
 RTX_SYMBOLS = ["rtx_last_error", "rtx_context_create", "rtx_context_destroy", "rtx_context_synchronize",
                "rtx_context_set_debug_queue_divisor", "rtx_context_set_workspace_limit",
-               "rtx_context_set_cull_threshold", "rtx_context_set_measured_queues", "rtx_context_queue_bytes",
+               "rtx_context_set_cull_threshold", "rtx_context_set_lane_walk", "rtx_context_set_measured_queues", "rtx_context_queue_bytes",
                "rtx_scene_upload", "rtx_scene_destroy", "rtx_scene_features", "rtx_render", "rtx_render_8bit", "rtx_render_device", "rtx_part_rows", "rtx_render_part_device", "rtx_render_device_noalloc", "rtx_trace_rays",
                "rtx_probe_rays", "rtx_selfcheck_division", "rtx_selfcheck_pow", "rtx_generate_rays", "rtx_quantize_u8_device", "rtx_device_info", "rtx_multi_last_error", "rtx_multi_create",
                "rtx_multi_destroy", "rtx_multi_device_count", "rtx_multi_scene_upload", "rtx_multi_scene_destroy", "rtx_multi_render"]
@@ -297,6 +298,9 @@ class Context:
 
     def set_cull_threshold(self, min_bounded_objects):
         _check(rtx_context_set_cull_threshold(self.h, min_bounded_objects))
+
+    def set_lane_walk(self, enabled):
+        _check(rtx_context_set_lane_walk(self.h, 1 if enabled else 0))
 
     def info(self):
         name = C.create_string_buffer(256)
@@ -437,7 +441,7 @@ class Scene:
         _check(rtx_scene_features(self.h, C.byref(bits)))
         v = bits.value
         return dict(reflective=bool(v & 1), transparent=bool(v & 2), all_cast_shadows=bool(v & 4), patterns=bool(v & 8),
-                    bounding_sphere_tests=bool(v & 16))
+                    bounding_sphere_tests=bool(v & 16), groups=bool(v & 32), lane_walk=bool(v & 64))
 
     def close(self):
         if self.h:

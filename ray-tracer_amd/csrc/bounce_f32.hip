@@ -3,6 +3,6 @@
 
 namespace rtx {
 template hipError_t launch_bounce<float>(uint32_t, hipStream_t, const SceneDev<float> &, const QueueDev<float> &, const QueueDev<float> &,
-                                       uint32_t, uint32_t, float *, StatShard *, uint32_t, uint32_t, int);
+                                       uint32_t, uint32_t, float *, StatShard *, uint32_t, uint32_t);
 }  // namespace rtx
 

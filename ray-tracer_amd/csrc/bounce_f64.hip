@@ -7,6 +7,6 @@
 
 namespace rtx {
 template hipError_t launch_bounce<double>(uint32_t, hipStream_t, const SceneDev<double> &, const QueueDev<double> &, const QueueDev<double> &,
-                                       uint32_t, uint32_t, double *, StatShard *, uint32_t, uint32_t, int);
+                                       uint32_t, uint32_t, double *, StatShard *, uint32_t, uint32_t);
 }  // namespace rtx
 

@@ -166,9 +166,6 @@ RT_DEV void sort_by_hit_object(QueueChunk *lds, uint32_t *hist2, uint32_t round,
 //      computes.
 // COLD_LDS: the launch comes with cold_lds_bytes() of dynamic LDS and the scene has at most
 // kColdLdsObjects objects (launch_bounce sees to both).
-#ifndef RTX_BOUNCE_SORT
-#define RTX_BOUNCE_SORT 1
-#endif
 constexpr uint32_t kWideRays = 65536u;  // a level of at most this many rays gets one ray per wave (scenes with the sphere hierarchy)
 template <typename R, uint32_t SF, bool COLD_LDS>
 __global__ void __launch_bounds__(bounce_block<R>(SF))
@@ -180,7 +177,7 @@ k_bounce(BounceArgs<R> args_in_kernarg_segment)
     // active per vector instruction and 3 % fewer vector instructions in either precision, which the two
     // barriers per round give back in f64 (1.84 against 1.82 ms; rounds are twice as long there and the waves of
     // a workgroup drift further apart) and do not in f32 (1.165 against 1.185 ms).
-    constexpr bool kSort = RTX_BOUNCE_SORT != 0 && (SF & SF_CULL) == 0 && sizeof(R) == 4;
+    constexpr bool kSort = (SF & SF_CULL) == 0 && sizeof(R) == 4;
     constexpr bool kTrack = (SF & SF_TRANSPARENT) != 0;
     constexpr uint32_t kStride = kSliceChunks<R, kSort, kTrack>;
     __shared__ QueueChunk lds[(kPiece / 64u) * kStride * 64u];
@@ -324,14 +321,12 @@ RT_DEV void entry_load(const QueueDev<R> &q, uint32_t sub, uint32_t idx, V3<R> &
     weight = v[6];
     pixel = pixel_bits_load<R>(v[7]);
 }
-#ifndef RTX_TREE_WIDE_RAYS
-#define RTX_TREE_WIDE_RAYS 131072u
-#endif
-#ifndef RTX_TREE_WIDE_RAYS_GLASS
-#define RTX_TREE_WIDE_RAYS_GLASS 4096u
-#endif
-constexpr uint32_t kTreeWideRays = RTX_TREE_WIDE_RAYS, kTreeWideRaysGlass = RTX_TREE_WIDE_RAYS_GLASS;  // a level of at most this many rays gets one ray per wave here
-template <typename R, uint32_t SF, int WALK>
+// Below how many rays a level gets one ray per wave (measured on 4K frames of 10 002 objects: the 35 000-ray level
+// of the opaque scene takes 0.41 ms lane by lane and 0.53 ms a wave per ray, its 3 500-ray level 0.27 and 0.06 ms;
+// with 25 glass objects the levels of 60 000 - 90 000 rays take 0.5 - 0.6 ms lane by lane and 4 ms a wave per ray,
+// whose container walks are made by 64 lanes that hold the same ray).
+constexpr uint32_t kTreeWideRays = 24576u, kTreeWideRaysGlass = 4096u;  // a level of at most this many rays gets one ray per wave here
+template <typename R, uint32_t SF>
 __global__ void __launch_bounds__(kLaneTreeBlock)
 k_bounce_tree(BounceArgs<R> args_in_kernarg_segment)
 {
@@ -404,7 +399,7 @@ k_bounce_tree(BounceArgs<R> args_in_kernarg_segment)
                 });
             }
         } else if (valid) {
-            nd = trace_node<R, SF, false, WALK, false>(A.S, nullptr, ro, rd, A.remaining, [&](const Node<R> &c) {
+            nd = trace_node<R, SF, false, WALK_LANE, false>(A.S, nullptr, ro, rd, A.remaining, [&](const Node<R> &c) {
                 queue_push2(A.out_q, sub, c.has_reflect, c.over_point, c.reflectv, w * c.reflect_factor, c.has_refract,
                             c.under_point, c.refract_dir, w * c.refract_factor, px_index);
             });
@@ -423,7 +418,7 @@ k_bounce_tree(BounceArgs<R> args_in_kernarg_segment)
 template <typename R>
 hipError_t launch_bounce(uint32_t sf, hipStream_t stream, const SceneDev<R> &scene, const QueueDev<R> &in_q,
                              const QueueDev<R> &out_q, uint32_t remaining, uint32_t level, R *fb, StatShard *stats,
-                             uint32_t resident_blocks, uint32_t longest, int tree_walk)
+                             uint32_t resident_blocks, uint32_t longest)
 {
     if ((sf & (SF_REFLECTIVE | SF_TRANSPARENT)) == 0 || in_q.cap_sub == 0) return hipSuccess;  // nothing can be queued
     const uint32_t n_sub = in_q.sub_mask + 1;
@@ -436,10 +431,7 @@ hipError_t launch_bounce(uint32_t sf, hipStream_t stream, const SceneDev<R> &sce
         if (scene.q_n == 0 || scene.q_n > kLaneTreeMaxNodes || !scene.q_nodes) return hipErrorInvalidValue;
 #define RTX_CALL(SFV)                                                                                   \
     if constexpr (((SFV) & (SF_REFLECTIVE | SF_TRANSPARENT)) != 0 && ((SFV) & SF_CULL) != 0)            \
-    {                                                                                                   \
-        if (tree_walk == WALK_LANE) hipLaunchKernelGGL((k_bounce_tree<R, SFV | SF_PATTERN, WALK_LANE>), grid, dim3(piece), 0, stream, args); \
-        else hipLaunchKernelGGL((k_bounce_tree<R, SFV | SF_PATTERN, WALK_TREE>), grid, dim3(piece), 0, stream, args); \
-    }
+        hipLaunchKernelGGL((k_bounce_tree<R, SFV | SF_PATTERN>), grid, dim3(piece), 0, stream, args);
         RTX_SF_SWITCH(sf, RTX_CALL)
 #undef RTX_CALL
         return hipGetLastError();

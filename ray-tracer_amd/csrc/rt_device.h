@@ -707,10 +707,13 @@ struct PrimSphereCull {
 // them); what a finished batch found shortens the reach of the next (wave_best).
 // Same tests, same spheres, same exact intersections as the other walks; the order in which
 // objects are met differs, and ties between equal t are settled by World index, not by order.
-// WALK_WAVE, WALK_WIDE: bounding spheres fetched from memory; WALK_LANE, WALK_TREE, WALK_TREE_WIDE: the packed
-// hierarchy in LDS walked per lane, per wave, and by a whole wave for one ray
-enum : int { WALK_WAVE = 0, WALK_LANE = 1, WALK_WIDE = 2, WALK_TREE = 3, WALK_TREE_WIDE = 4 };
-constexpr bool walk_in_lds(int walk) { return walk == WALK_LANE || walk == WALK_TREE || walk == WALK_TREE_WIDE; }
+// WALK_WAVE, WALK_WIDE: bounding spheres fetched from memory, a wave at a time for its 64 rays, or by a whole wave
+// for one ray; WALK_LANE, WALK_TREE_WIDE: the packed hierarchy in LDS, every lane for its own ray, or a whole wave
+// for one ray.  (A wave at a time over the packed hierarchy was measured too: a wave of 64 unrelated rays visits
+// most of a scene's clusters whatever the spheres are fetched from -- 2.3 against 0.83 ms on the first level of a
+// 4K frame of 10 002 objects.)
+enum : int { WALK_WAVE = 0, WALK_LANE = 1, WALK_WIDE = 2, WALK_TREE_WIDE = 4 };
+constexpr bool walk_in_lds(int walk) { return walk == WALK_LANE || walk == WALK_TREE_WIDE; }
 constexpr bool walk_is_wide(int walk) { return walk == WALK_WIDE || walk == WALK_TREE_WIDE; }
 template <typename T> RT_DEV T wave_min(T v)
 {
@@ -820,6 +823,35 @@ struct LaneTreeCull {
         const uint32_t qr = hi >> 16;
         b.r = qr == 0xffffu ? Num<float>::inf : __builtin_fmaf((float)qr, step, extra_r);
         return may_hit<float, false>(b, cr, rch);
+    }
+    // Two neighbouring spheres at once, two floats to an instruction (v_pk_*_f32: the one place where the
+    // single-precision vector unit does two operations per lane and cycle): bit 0 of the answer for `node`,
+    // bit 1 for `node + 1`.  The expressions are may_hit's for rays that count from their origin on.
+    typedef float Pair __attribute__((ext_vector_type(2)));
+    RT_DEV uint32_t test_pair(uint32_t node, float rch) const
+    {
+        const unsigned long long qa = nodes[node], qb = nodes[node + 1u];
+        const uint32_t la = (uint32_t)qa, ha = (uint32_t)(qa >> 32), lb = (uint32_t)qb, hb = (uint32_t)(qb >> 32);
+        const Pair qx = { (float)(la & 0xffffu), (float)(lb & 0xffffu) }, qy = { (float)(la >> 16), (float)(lb >> 16) },
+                   qz = { (float)(ha & 0xffffu), (float)(hb & 0xffffu) }, qr = { (float)(ha >> 16), (float)(hb >> 16) };
+        const Pair st = { step, step };
+        // centre - origin of the ray, and the radius
+        const Pair mx = __builtin_elementwise_fma(qx, st, Pair{ base[0] - cr.o.x, base[0] - cr.o.x });
+        const Pair my = __builtin_elementwise_fma(qy, st, Pair{ base[1] - cr.o.y, base[1] - cr.o.y });
+        const Pair mz = __builtin_elementwise_fma(qz, st, Pair{ base[2] - cr.o.z, base[2] - cr.o.z });
+        Pair r = __builtin_elementwise_fma(qr, st, Pair{ extra_r, extra_r });
+        r.x = (ha >> 16) == 0xffffu ? Num<float>::inf : r.x;
+        r.y = (hb >> 16) == 0xffffu ? Num<float>::inf : r.y;
+        const Pair ux = { cr.u.x, cr.u.x }, uy = { cr.u.y, cr.u.y }, uz = { cr.u.z, cr.u.z };
+        const Pair tc = __builtin_elementwise_fma(mz, uz, __builtin_elementwise_fma(my, uy, mx * ux));
+        const Pair m2 = __builtin_elementwise_fma(mz, mz, __builtin_elementwise_fma(my, my, mx * mx));
+        const Pair r2 = r * r;
+        const Pair slack = { -Num<float>::cull_slack, -Num<float>::cull_slack };
+        const Pair out = __builtin_elementwise_fma(slack, m2, __builtin_elementwise_fma(-tc, tc, m2)) - r2;
+        const Pair behind = __builtin_elementwise_min(-tc, m2 - r2);
+        const Pair far_ = __builtin_elementwise_fma(slack, __builtin_elementwise_abs(tc), tc - r) - Pair{ rch, rch };
+        const Pair worst = __builtin_elementwise_max(__builtin_elementwise_max(out, behind), far_);
+        return cr.dead ? 0u : ((worst.x > 0.0f ? 0u : 1u) | (worst.y > 0.0f ? 0u : 2u));
     }
     RT_DEV bool stopped() const { return stop && *stop; }
     // for the walk of a whole wave (walk_table): the same sphere for every lane, its own answer for each
@@ -936,8 +968,8 @@ RT_DEV void lane_tree_walk_table(const Rec *recs, uint32_t n, uint32_t slot0, ui
                 const float rch = keep.reach();
                 const uint32_t c0 = g * kCluster;
 #pragma unroll
-                for (uint32_t j = 0; j < kCluster; ++j)
-                    if (c0 + j < n_cl && keep.test(keep.cl0 + cluster0 + c0 + j, rch)) clusters |= 1u << j;
+                for (uint32_t j = 0; j < kCluster; j += 2u) clusters |= keep.test_pair(keep.cl0 + cluster0 + c0 + j, rch) << j;
+                if (c0 + kCluster > n_cl) clusters &= (1u << (n_cl - c0)) - 1u;  // (entries past the table are padding)
             }
             while (clusters != 0u) {
                 const uint32_t c = g * kCluster + (uint32_t)__builtin_ctz(clusters);
@@ -947,8 +979,8 @@ RT_DEV void lane_tree_walk_table(const Rec *recs, uint32_t n, uint32_t slot0, ui
                     const float rch = keep.reach();
                     const uint32_t i0 = c * kCluster;
 #pragma unroll
-                    for (uint32_t j = 0; j < kCluster; ++j)
-                        if (i0 + j < n && keep.test(slot0 + i0 + j, rch)) members |= 1u << j;
+                    for (uint32_t j = 0; j < kCluster; j += 2u) members |= keep.test_pair(slot0 + i0 + j, rch) << j;
+                    if (i0 + kCluster > n) members &= (1u << (n - i0)) - 1u;
                 }
                 while (members != 0u) {
                     const uint32_t i = c * kCluster + (uint32_t)__builtin_ctz(members);
@@ -1671,7 +1703,7 @@ RT_DEV bool is_shadowed(const SceneDev<R> &S, V3<R> p, V3<R> dir, R distance)
         };
         if constexpr (CULL && walk_in_lds(WALK)) {
             const LaneTreeCull<R> keep = lane_tree_cull<R>(S, p, dir, nullptr, distance, &shadowed);
-            walk_scene<R, CHAIN, WALK == WALK_TREE ? WALK_WAVE : WALK>(S, p, dir, keep, per);
+            walk_scene<R, CHAIN, WALK>(S, p, dir, keep, per);
             if constexpr (WALK == WALK_TREE_WIDE) shadowed = __ballot(shadowed) != 0ull;  // any lane's object
         } else if constexpr (CULL) {
             const SphereCull<R, false> keep = { S.bnd, S.cl, S.grp, cull_ray<R, false>(S, p, dir), nullptr, distance, &shadowed };

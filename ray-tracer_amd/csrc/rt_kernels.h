@@ -175,18 +175,9 @@ RT_DEV void primary_ray(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> ro, V
 // f64 operations behind two rounds of scalar loads, and more of them side by side is what hides that.
 // The variants with the tests spill at 6 waves (40-130 bytes of scratch; camera launch of a 10 002-object
 // frame 1.05 -> 1.16 ms) and keep the compiler's choice.
-#ifndef RTX_CAM_WAVES
-#define RTX_CAM_WAVES 7u
-#endif
-#ifndef RTX_CAM_WAVES_CULL
-#define RTX_CAM_WAVES_CULL 1u
-#endif
-constexpr uint32_t camera_waves(uint32_t sf) { return (sf & SF_CULL) ? RTX_CAM_WAVES_CULL : RTX_CAM_WAVES; }
-#ifndef RTX_CAMERA_ATTR
-#define RTX_CAMERA_ATTR __attribute__((amdgpu_waves_per_eu(camera_waves(SF))))
-#endif
+constexpr uint32_t camera_waves(uint32_t sf) { return (sf & SF_CULL) ? 1u : 7u; }
 template <typename R, uint32_t SF, bool OUT8 = false, bool BANDED = false>
-__global__ void __launch_bounds__(kCamBlock<R>) RTX_CAMERA_ATTR
+__global__ void __launch_bounds__(kCamBlock<R>) __attribute__((amdgpu_waves_per_eu(camera_waves(SF))))
 k_primary_camera(CameraDev<R> cam, SceneDev<R> S, PrimScene<R> P, uint32_t local0, uint32_t n_rows,
                  uint32_t remaining, void *__restrict__ fb, QueueDev<R> out_q, StatShard *__restrict__ stats, RowMap map,
                  uint32_t format)

@@ -16,37 +16,22 @@ constexpr uint32_t kBlock = 256;
 // thread without a loop (which keeps loop-carried state out of the scalar registers the object
 // records need).  Measured on the glass and 10k-object scenes, f64 rays (dearer per ray) are
 // best with 128, f32 rays with 256.
-#ifndef RTX_RAY_BLOCK_F64
-#define RTX_RAY_BLOCK_F64 128u
-#endif
-#ifndef RTX_RAY_BLOCK_F32
-#define RTX_RAY_BLOCK_F32 256u
-#endif
-template <typename R> constexpr uint32_t kRayBlock = sizeof(R) == 8 ? RTX_RAY_BLOCK_F64 : RTX_RAY_BLOCK_F32;
+template <typename R> constexpr uint32_t kRayBlock = sizeof(R) == 8 ? 128u : 256u;
 // Rays per piece of a bounce launch (and threads per workgroup of the bounce kernel).  Scenes without
 // bounding-sphere tests stage their shading table in LDS per workgroup and do better with 256 threads
 // in f64 as well (4K glass frame 1.84 -> 1.78 ms); with the tests, whose waves differ widely in length,
 // 256 is slower (10k-object frame 5.97 -> 6.4 ms).
-#ifndef RTX_BOUNCE_BLOCK_F64_SMALL_SCENE
-#define RTX_BOUNCE_BLOCK_F64_SMALL_SCENE 256u
-#endif
 template <typename R> constexpr uint32_t bounce_block(uint32_t sf)
 {
     if (sf & SF_LANE_TREE) return kLaneTreeBlock;
-    return sizeof(R) == 8 ? ((sf & 16u /* SF_CULL */) ? RTX_RAY_BLOCK_F64 : RTX_BOUNCE_BLOCK_F64_SMALL_SCENE) : RTX_RAY_BLOCK_F32;
+    return sizeof(R) == 8 ? ((sf & SF_CULL) ? 128u : 256u) : 256u;
 }
 // Threads per workgroup of the camera kernel.  Its waves share nothing.  In f64 one wave per
 // workgroup: single waves fill the chip's last round more evenly than groups of four (4K headline
 // frame: 61 -> 58.5 us).  The chip starts about 4.6 workgroups per nanosecond whatever their size
 // (tools/wave_rate.hip: 28 us for the 129 600 one-wave workgroups of a 4K frame that do nothing, 8 us
 // for 32 400 of four waves), which a frame of short f32 waves runs into.
-#ifndef RTX_CAM_BLOCK_F64
-#define RTX_CAM_BLOCK_F64 64u
-#endif
-#ifndef RTX_CAM_BLOCK_F32
-#define RTX_CAM_BLOCK_F32 64u
-#endif
-template <typename R> constexpr uint32_t kCamBlock = sizeof(R) == 8 ? RTX_CAM_BLOCK_F64 : RTX_CAM_BLOCK_F32;
+template <typename R> constexpr uint32_t kCamBlock = 64u;
 
 // Wave-sized pieces of the camera kernel's image for n_rows rows of hsize pixels.  Without
 // bounding-sphere tests a wave takes one 64-pixel row segment (its framebuffer stores are one
@@ -103,11 +88,11 @@ struct Launch {
 template <typename R>
 hipError_t launch_bounce(uint32_t sf, hipStream_t stream, const SceneDev<R> &scene, const QueueDev<R> &in_q,
                          const QueueDev<R> &out_q, uint32_t remaining, uint32_t level, R *fb, StatShard *stats,
-                         uint32_t resident_blocks, uint32_t longest = 0, int tree_walk = 3);
+                         uint32_t resident_blocks, uint32_t longest = 0);
 extern template hipError_t launch_bounce<double>(uint32_t, hipStream_t, const SceneDev<double> &, const QueueDev<double> &,
-                                                 const QueueDev<double> &, uint32_t, uint32_t, double *, StatShard *, uint32_t, uint32_t, int);
+                                                 const QueueDev<double> &, uint32_t, uint32_t, double *, StatShard *, uint32_t, uint32_t);
 extern template hipError_t launch_bounce<float>(uint32_t, hipStream_t, const SceneDev<float> &, const QueueDev<float> &,
-                                                const QueueDev<float> &, uint32_t, uint32_t, float *, StatShard *, uint32_t, uint32_t, int);
+                                                const QueueDev<float> &, uint32_t, uint32_t, float *, StatShard *, uint32_t, uint32_t);
 
 // Size of the file-scope device array behind rtx_render_device_noalloc (scratch.hip), and its
 // device address on the current device.

@@ -80,10 +80,7 @@ struct alignas(sizeof(R) * 4) BoundRec {
 // bounding sphere (a cluster), every kCluster consecutive clusters share a third (a group).
 // A ray tests n / kCluster^2 group spheres, then the clusters of the groups it meets, then the
 // members of the clusters it meets.
-#ifndef RTX_CLUSTER
-#define RTX_CLUSTER 16
-#endif
-constexpr uint32_t kCluster = RTX_CLUSTER;
+constexpr uint32_t kCluster = 16;
 // The same hierarchy once more, 8 bytes a sphere: centre and radius in units of `step` from `base`
 // (SceneDev::q_*), the centre rounded to the nearest unit and the radius rounded up by more than the
 // centre can have moved, so that the packed sphere holds the stored one.  r = 0xffff: unbounded.
@@ -94,10 +91,7 @@ struct QuantNode {
     uint16_t r;
 };
 constexpr uint32_t kLaneTreeMaxNodes = 11776;  // 92 KB of the 160 KB a workgroup can have
-#ifndef RTX_LANE_TREE_BLOCK
-#define RTX_LANE_TREE_BLOCK 1024
-#endif
-constexpr uint32_t kLaneTreeBlock = RTX_LANE_TREE_BLOCK;  // threads of a workgroup that holds the packed hierarchy (one per CU)
+constexpr uint32_t kLaneTreeBlock = 1024;      // threads of a workgroup that holds the packed hierarchy (one per CU: 4 waves per SIMD)
 
 // ---- primary-ray tables -----------------------------------------------------------------
 // Every primary ray starts at the camera, so each object's object-space ray origin and the
@@ -255,15 +249,9 @@ struct QueueDev {
 
 // Per-level counters, one block of shards per render call (summed on the host).
 // lanes of a lightly loaded chip: 1024 SIMDs x 4 waves x 64 (k_bounce spreads short levels over them)
-#ifndef RTX_SPREAD_LANES
-#define RTX_SPREAD_LANES (1024u * 4u * 64u)
-#endif
-constexpr uint32_t kSpreadLanes = RTX_SPREAD_LANES;
+constexpr uint32_t kSpreadLanes = 1024u * 4u * 64u;
 // camera rays of scenes with the sphere hierarchy are walked a wave at a time (beam_walk_table)
-#ifndef RTX_BEAM_WALK
-#define RTX_BEAM_WALK 1
-#endif
-constexpr bool kBeamWalk = RTX_BEAM_WALK != 0;
+constexpr bool kBeamWalk = true;
 constexpr int kStatShards = 256;
 struct StatShard {
     unsigned long long hits[8];  // shaded hits (= is_shadowed calls) per recursion level

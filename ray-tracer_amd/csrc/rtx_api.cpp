@@ -18,6 +18,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -131,7 +132,6 @@ struct rtx_context {
     uint32_t bounce_blocks_cull = 65536u;  // the same for scenes with bounding-sphere tests: one per piece the queue can hold, up to this many
     uint32_t bounce_blocks_lane = 512u;    // and for the kernel that keeps the packed hierarchy in LDS (one resident workgroup per CU)
     bool lane_tree = true;                 // scenes uploaded from now on may use that kernel
-    int tree_walk = 1;                     // how it walks long levels: 1 every lane for itself, 3 a wave at a time
     void *scratch = nullptr;         // this device's copy of the file-scope array of scratch.hip
     size_t scratch_bytes = 0;
     uint32_t *overflow_host = nullptr;  // pinned word the kernels set when a ray queue overflows
@@ -248,7 +248,10 @@ void trim_idle_queues(rtx_context *ctx, const Workspace *keep)
 {
     std::lock_guard<std::mutex> lk(ctx->mu);
     for (auto &s : ctx->slots) {
-        if (s->busy || s->pending || &s->ws == keep) continue;
+        if (s->busy || &s->ws == keep) continue;
+        // work a call left in flight may have finished since: then nothing refers to the queues any more
+        if (s->pending && hipEventQuery(s->done) == hipSuccess) s->pending = false;
+        if (s->pending) continue;
         if (s->ws.queues) (void)hipFree(s->ws.queues);
         if (s->ws.queues_even) (void)hipFree(s->ws.queues_even);
         s->ws.queues = s->ws.queues_even = nullptr;
@@ -290,7 +293,12 @@ int copy_to_host(Slot *slot, hipStream_t stream, void *dst, const void *src, siz
         std::thread helpers[kCopyThreads - 1];
         for (int k = 1; k < kCopyThreads; ++k) {
             const size_t a = (size_t)k * part;
-            if (a < len) helpers[k - 1] = std::thread([=] { std::memcpy(out + a, in + a, std::min(part, len - a)); });
+            if (a >= len) continue;
+            try {
+                helpers[k - 1] = std::thread([=] { std::memcpy(out + a, in + a, std::min(part, len - a)); });
+            } catch (const std::system_error &) {  // no thread to be had: this one copies the piece itself
+                std::memcpy(out + a, in + a, std::min(part, len - a));
+            }
         }
         std::memcpy(out, in, std::min(part, len));
         for (auto &h : helpers)
@@ -635,7 +643,7 @@ QuantTree quantize_tree(const Tables<double> &t)
 {
     QuantTree q;
     const size_t total = t.bnd.size() + t.cl.size() + t.grp.size();
-    if (t.grp.empty() || total > kLaneTreeMaxNodes) return q;
+    if (t.grp.empty() || total + 16 > kLaneTreeMaxNodes) return q;  // (the walk reads up to 15 entries past a table's last)
     double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
     bool any = false;
     for (const auto *v : { &t.bnd, &t.cl, &t.grp })
@@ -1051,8 +1059,14 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Workspace &ws, hipEv
             }
             limit /= 2;
             if (limit < ((size_t)64 << 20)) return fail(RTX_ERR_DEVICE, "out of device memory for the secondary-ray queues (%zu bytes)", plan.bytes);
-            rc = plan_frame<R>(limit, scene->sf, max_depth, W, n_units, &plan);
+            // (a measured frame plans its first level alone, as above: the deeper ones are sized as they come)
+            rc = plan_frame<R>(limit, scene->sf, measured ? 1u : max_depth, W, n_units, &plan);
             if (rc) return rc;
+            if (measured) {
+                plan.levels = max_depth;
+                plan.even_entries = 0;
+                plan.bytes = (size_t)(plan.odd_entries * 8 * sizeof(R));
+            }
         }
     }
     if (format != 0u && plan.levels != 0u) return fail(RTX_ERR_INVALID, "internal: 8-bit output straight from a frame with secondary rays");
@@ -1124,8 +1138,7 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Workspace &ws, hipEv
                 at += b_pbnd + b_pcl + b_pgrp;
             }
         }
-        static const double beam_sin = [] { const char *e = std::getenv("RTX_SHADOW_BEAM_SIN"); return e ? std::atof(e) : 0.1; }();
-        prim.shadow_beam_sin = (R)beam_sin;
+        prim.shadow_beam_sin = R(0.1);
         prim.n_sph = SD.n_sph; prim.n_pln = SD.n_pln; prim.n_cub = SD.n_cub; prim.n_cyl = SD.n_cyl; prim.n_con = SD.n_con;
     }
     // The first launch of a frame zeroes the queue and hit counters and fills the primary-ray tables.
@@ -1190,7 +1203,7 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Workspace &ws, hipEv
             HIP_TRY(launch_bounce<R>(scene->sf, stream, S, queue_at(L), queue_at(L + 1), max_depth - L, L, fb, ws.shards,
                                      (scene->sf & SF_LANE_TREE) ? ctx->bounce_blocks_lane
                                                                 : (scene->sf & SF_CULL) ? ctx->bounce_blocks_cull : ctx->bounce_blocks,
-                                     0u, ctx->tree_walk));
+                                     0u));
             ++launches;
         }
         done += cam ? units * W : units;
@@ -1458,10 +1471,6 @@ int rtx_context_create(int device_id, rtx_context **out)
     // memory (48 GB of 288) lets such a frame run as one chunk and leaves room for several
     // concurrent render calls.
     ctx->workspace_limit = std::max<size_t>((size_t)8 << 30, prop.totalGlobalMem / 6);
-    if (const char *e = std::getenv("RTX_CULL_MIN_OBJECTS")) {
-        int v = std::atoi(e);
-        if (v >= 0) ctx->cull_min_objects = (uint32_t)v;
-    }
     // Workgroups of a bounce launch: each loops over its share of a sub-queue's rays.  The chip holds about
     // 10 of them per CU at once (f64: 2 waves of 85 registers each); three times that many, shorter ones
     // keep it filled to the end of the launch: pieces of 128 rays differ several-fold in what they cost
@@ -1469,24 +1478,6 @@ int rtx_context_create(int device_id, rtx_context **out)
     // piece, 2.57).  Handing the pieces out by ticket instead was slower than this fixed split.
     ctx->bounce_blocks = (uint32_t)ctx->cu_count * 30u;
     ctx->bounce_blocks_lane = (uint32_t)ctx->cu_count;
-    if (const char *e = std::getenv("RTX_BOUNCE_BLOCKS")) {
-        int v = std::atoi(e);
-        if (v >= 1) ctx->bounce_blocks = (uint32_t)v;
-    }
-    if (const char *e = std::getenv("RTX_BOUNCE_BLOCKS_LANE")) {
-        int v = std::atoi(e);
-        if (v >= 1) ctx->bounce_blocks_lane = (uint32_t)v;
-    }
-    if (const char *e = std::getenv("RTX_LANE_TREE")) ctx->lane_tree = std::atoi(e) != 0;
-    if (const char *e = std::getenv("RTX_TREE_WALK")) ctx->tree_walk = std::atoi(e) == 1 ? 1 : 3;
-    if (const char *e = std::getenv("RTX_BOUNCE_BLOCKS_CULL")) {
-        int v = std::atoi(e);
-        if (v >= 1) ctx->bounce_blocks_cull = (uint32_t)v;
-    }
-    if (const char *e = std::getenv("RTX_BLOCKS_PER_CU")) {
-        int v = std::atoi(e);
-        if (v >= 1 && v <= 64) ctx->blocks_per_cu = (uint32_t)v;
-    }
     {
         DeviceGuard guard(device_id);
         if (!guard.ok) return fail(RTX_ERR_DEVICE, "hipSetDevice(%d) failed", device_id);
@@ -1527,6 +1518,11 @@ int rtx_context_synchronize(rtx_context *ctx)
             if (s->pending) waits.push_back(s->done);
     }
     for (hipEvent_t e : waits) HIP_TRY(hipEventSynchronize(e));
+    {   // what was waited for is no longer in flight: those slots' queues may be given back when memory runs short
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        for (auto &s : ctx->slots)
+            if (!s->busy && s->pending && hipEventQuery(s->done) == hipSuccess) s->pending = false;
+    }
     return check_overflow(ctx);
 }
 
@@ -1563,6 +1559,14 @@ int rtx_context_set_workspace_limit(rtx_context *ctx, size_t bytes)
     if (bytes < ((size_t)1 << 20)) return fail(RTX_ERR_INVALID, "workspace limit below 1 MiB");
     std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->workspace_limit = bytes;
+    return RTX_OK;
+}
+
+int rtx_context_set_lane_walk(rtx_context *ctx, int enabled)
+{
+    if (!ctx) return fail(RTX_ERR_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->lane_tree = enabled != 0;
     return RTX_OK;
 }
 

@@ -189,6 +189,26 @@ def test_8k_multi_light_frame_from_eight_row_tiles(orc, rta):
         want = orc.color_at(ow, _camera_rays(orc, ocam, xs, ys))
         assert np.abs(a[ys, xs] - want).max() <= TOL
         assert st["rays_per_level"][0] == W * H and st["rays_per_level"][5] > 0
+        # ... and as it ships (rtx_multi_render, bench.py): the 10-row bands dealt out in turn to eight parts
+        # (band b to part b mod 8, src/scenes/camera.rs:177), each part's bands back to back in its own buffer
+        # (rtx_render_part_device), values and RGBA8; put back in place they are the whole frame
+        part_rays = 0
+        bands = np.arange((H + 9) // 10)
+        quant = orc.quantize_u8(a)
+        for k in range(8):
+            rows = rta.rtx_part_rows(H, 10, 8, k)
+            image_rows = np.concatenate([np.arange(b * 10, min(b * 10 + 10, H)) for b in bands[k::8]])
+            assert rows == len(image_rows)
+            ps = {}
+            rta.render_part_device(ctx, scene, cd, 5, rta.F64, 10, 8, k, 0, tiled.ptr.value, rows * W * 24, stream.value, ps)
+            part_rays += ps["color_rays"] + ps["shadow_rays"]
+            got = tiled.read((rows, W, 3), np.float64, stream)
+            assert np.abs(got - a[image_rows]).max() <= 1e-12, "part %d of 8" % k
+            rta.render_part_device(ctx, scene, cd, 5, rta.F64, 10, 8, k, rta.PIXELS_RGBA8, tiled.ptr.value, rows * W * 4, stream.value)
+            got8 = tiled.read((rows, W, 4), np.uint8, stream)
+            diff = np.abs(got8[..., :3].astype(np.int16) - quant[image_rows].astype(np.int16))
+            assert diff.max() <= 1 and (diff != 0).mean() < 1e-4 and (got8[..., 3] == 255).all()
+        assert part_rays == st["color_rays"] + st["shadow_rays"]
     finally:
         hip.hipStreamDestroy(stream)
         whole.free()

@@ -125,3 +125,32 @@ def test_fast_path(rta):
         close = np.abs(a - b).max(axis=2) <= 1.0 / 255.0
         assert close.mean() >= 0.999, (name, close.mean())
         assert abs(sa["shadow_rays"] - sb["shadow_rays"]) <= 20, name
+
+
+@pytest.mark.parametrize("glass_every", [0, 60])
+def test_lane_walk_changes_nothing(rta, glass_every):
+    """Secondary rays of a scene whose packed sphere hierarchy fits LDS walk it lane by lane (and a wave per
+    ray on short levels); with that switched off a wave walks the spheres in memory for its 64 rays.  The
+    packed spheres hold the stored ones, so the same objects reach an exact intersection: frames equal to the
+    last bit of every hit decision (colours to the few ulps the order of the framebuffer additions moves
+    them), counters equal, in both precisions, with and without glass (whose container bookkeeping is a
+    backward walk of its own: src/scenes/world.rs:253-285)."""
+    world = _world(rta.api, 2500, glass_every=glass_every)
+    flat = rta.flatten(world)
+    cams = {name: _camera(rta.api, 168, 94, VIEWS[name]) for name in ("front", "inside", "far_side")}
+    for precision, tol in ((rta.F64, 1e-12), (rta.F32, 2e-5)):
+        got = {}
+        for lane in (True, False):
+            ctx = rta.Context()
+            ctx.set_lane_walk(lane)
+            scene = rta.Scene(ctx, flat)
+            assert scene.features()["bounding_sphere_tests"] and scene.features()["lane_walk"] == lane
+            for name, cam in cams.items():
+                got[(lane, name)] = _frame(rta, ctx, scene, rta.camera_desc(cam), precision)
+            scene.close()
+            ctx.close()
+        for name in cams:
+            (a, sa), (b, sb) = got[(True, name)], got[(False, name)]
+            assert sa["rays_per_level"] == sb["rays_per_level"] and sa["shadow_rays"] == sb["shadow_rays"], name
+            assert sa["rays_per_level"][1] > 0 and (glass_every == 0 or sa["rays_per_level"][4] > 0)
+            assert np.abs(a.astype(np.float64) - b.astype(np.float64)).max() <= tol, name

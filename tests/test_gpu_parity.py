@@ -442,6 +442,47 @@ def test_f32_fast_path(orc, rta):
         assert ok >= 0.999, "%s %s: only %.4f of the pixels within 1/255" % (name, kw, ok)
 
 
+def test_f32_fast_path_on_grouped_objects(orc, rta):
+    """The fast path on worlds with transformed Groups, where it is below the 99.9 % it keeps elsewhere,
+    pinned at what it measures.  The reference shades a group's child with a copy whose transform is
+    rebuilt from merged transformation lists (src/shapes/traits.rs:35-44, src/shapes/groups.rs:73-84) and
+    is not the transform the ray was intersected with: the normal is then not the surface's, over_point
+    can lie inside the object, and the reflection and shadow rays that start there are decided by the last
+    bits of the hit point -- in any precision; f32 decides some of them the other way.  The plain objects
+    of the same frames keep their share (checked on the frame without the group's pixels)."""
+    from ray_tracer_amd import scenes
+    shares = {}
+    for nested in (False, True):
+        kw = dict(hsize=640, vsize=360, nested=nested)
+        gw, gcam = scenes.grouped_scene(rta.api, **kw)
+        ow, ocam = scenes.grouped_scene(orc.api, **kw)
+        got = rta.render_rows(gcam, gw, precision=rta.F32)
+        want = orc.parallel_render(ocam, ow)
+        ok = np.abs(orc.quantize_u8(got).astype(int) - orc.quantize_u8(want).astype(int)).max(axis=2) <= 1
+        shares[nested] = ok.mean()
+        # the f64 path has no such exception
+        exact = rta.render_rows(gcam, gw)
+        assert np.abs(exact - want).max() <= TOL
+    print("f32 share of pixels within 1/255 on the grouped scene: without nesting %.4f, nested %.4f" % (shares[False], shares[True]))
+    assert shares[False] >= 0.998 and shares[True] >= 0.997, shares
+    # randomised worlds (all shapes, all patterns, glass, twins) at four times their usual resolution: the same
+    # worlds without and with a transformed group that holds a nested, sheared one
+    from test_fuzz_parity import build_world
+    fuzz = {False: [], True: []}
+    for seed in range(2000, 2008):
+        for groups in (False, True):
+            gw, gcam = build_world(rta.api, seed, groups, res_scale=4)
+            ow, ocam = build_world(orc.api, seed, groups, res_scale=4)
+            got = rta.render_rows(gcam, gw, precision=rta.F32)
+            want = orc.parallel_render(ocam, ow)
+            both = np.isfinite(want).all(axis=2) & np.isfinite(got).all(axis=2)
+            ok = np.abs(orc.quantize_u8(got).astype(int) - orc.quantize_u8(want).astype(int)).max(axis=2) <= 1
+            fuzz[groups].append(ok[both].mean())
+    print("randomised worlds, share per frame: plain %s; with groups %s" % (np.round(fuzz[False], 4), np.round(fuzz[True], 4)))
+    assert min(fuzz[False]) >= 0.995 and np.mean(fuzz[False]) >= 0.998
+    assert min(fuzz[True]) >= 0.94 and np.mean(fuzz[True]) >= 0.985
+
+
 def test_edge_cases(orc, rta):
     api = rta.api
     # empty world: every pixel black, no light needed (nothing is ever hit)

@@ -77,3 +77,63 @@ def test_frames_beyond_the_fixed_array_are_refused(rta):
         buf.free()
         scene.close()
         ctx.close()
+
+
+def test_it_allocates_nothing_and_can_be_captured_in_a_graph(rta):
+    """What the entry point is for.  (a) Device memory in use is the same before and after a run of calls
+    (hipMemGetInfo; the array is resident from the first call of the process).  (b) One call recorded
+    between hipStreamBeginCapture and hipStreamEndCapture -- where an allocation or a synchronisation
+    would fail the capture -- and replayed twice as a graph gives the frame of rtx_render_device."""
+    from ray_tracer_amd import scenes
+    hip = hiprt.runtime()
+    hip.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    hip.hipStreamBeginCapture.argtypes = [C.c_void_p, C.c_int]
+    hip.hipStreamEndCapture.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    hip.hipGraphInstantiate.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    hip.hipGraphLaunch.argtypes = [C.c_void_p, C.c_void_p]
+    hip.hipGraphExecDestroy.argtypes = [C.c_void_p]
+    hip.hipGraphDestroy.argtypes = [C.c_void_p]
+    W, H, depth = 480, 270, 4
+    ctx = rta.Context()
+    stream = hiprt.new_stream(hip)
+    w, cam = scenes.glass_scene(rta.api, W, H)
+    scene = rta.Scene(ctx, rta.flatten(w))
+    cd = rta.camera_desc(cam)
+    nbytes = W * H * 24
+    a, b = hiprt.Buffer(hip, nbytes), hiprt.Buffer(hip, nbytes)
+    graph, graph_exec = C.c_void_p(), C.c_void_p()
+    try:
+        rta.render_device(ctx, scene, cd, depth, rta.F64, 0, H, a.ptr.value, nbytes, stream.value)
+        want = a.read((H, W, 3), np.float64, stream)
+        _noalloc(rta, ctx, scene, cd, depth, rta.F64, 0, H, b.ptr.value, nbytes, stream)  # first use: everything is resident now
+        assert hip.hipStreamSynchronize(stream) == 0
+        free0, free1, total = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        assert hip.hipMemGetInfo(C.byref(free0), C.byref(total)) == 0
+        for _ in range(5):
+            _noalloc(rta, ctx, scene, cd, depth, rta.F64, 0, H, b.ptr.value, nbytes, stream)
+        assert hip.hipStreamSynchronize(stream) == 0
+        assert hip.hipMemGetInfo(C.byref(free1), C.byref(total)) == 0
+        assert free1.value == free0.value, "device memory in use changed by %d bytes" % (free0.value - free1.value)
+        # (b) as a graph
+        assert hip.hipStreamBeginCapture(stream, 2) == 0  # hipStreamCaptureModeRelaxed
+        try:
+            _noalloc(rta, ctx, scene, cd, depth, rta.F64, 0, H, b.ptr.value, nbytes, stream)
+        finally:
+            assert hip.hipStreamEndCapture(stream, C.byref(graph)) == 0
+        assert graph.value, "nothing was captured"
+        assert hip.hipGraphInstantiate(C.byref(graph_exec), graph, None, None, 0) == 0
+        for _ in range(2):
+            b.fill(0xFF, stream)
+            assert hip.hipGraphLaunch(graph_exec, stream) == 0
+            got = b.read((H, W, 3), np.float64, stream)
+            assert np.abs(got - want).max() <= 1e-9
+    finally:
+        if graph_exec.value:
+            hip.hipGraphExecDestroy(graph_exec)
+        if graph.value:
+            hip.hipGraphDestroy(graph)
+        hip.hipStreamDestroy(stream)
+        a.free()
+        b.free()
+        scene.close()
+        ctx.close()
