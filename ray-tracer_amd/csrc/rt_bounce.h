@@ -322,64 +322,118 @@ RT_DEV void entry_load(const QueueDev<R> &q, uint32_t sub, uint32_t idx, V3<R> &
     pixel = pixel_bits_load<R>(v[7]);
 }
 // Below how many rays a level gets one ray per wave (measured on 4K frames of 10 002 objects: the 35 000-ray level
-// of the opaque scene takes 0.41 ms lane by lane and 0.53 ms a wave per ray, its 3 500-ray level 0.27 and 0.06 ms;
-// with 25 glass objects the levels of 60 000 - 90 000 rays take 0.5 - 0.6 ms lane by lane and 4 ms a wave per ray,
-// whose container walks are made by 64 lanes that hold the same ray).
-constexpr uint32_t kTreeWideRays = 24576u, kTreeWideRaysGlass = 4096u;  // a level of at most this many rays gets one ray per wave here
+// of the opaque scene takes 0.38 ms lane by lane and 0.30 ms a wave per ray, its 3 500-ray level 0.27 and 0.06 ms;
+// with 25 glass objects, whose deeper levels hold 60 000 - 90 000 rays each, the frame takes 3.5 ms with the
+// threshold at 4 096, 4.3 at 32 768 and 7.7 at 131 072: there the container walk of a wave per ray is made by 64
+// lanes that hold the same ray).
+constexpr uint32_t kTreeWideRays = 65536u, kTreeWideRaysGlass = 4096u;  // a level of at most this many rays gets one ray per wave here
+constexpr uint32_t kTreeStealTries = 4u;  // a wave ends after asking this many other sub-queues for rays in vain
 template <typename R, uint32_t SF>
 __global__ void __launch_bounds__(kLaneTreeBlock)
 k_bounce_tree(BounceArgs<R> args_in_kernarg_segment)
 {
     static_assert((SF & SF_CULL) != 0, "scenes with the sphere hierarchy");
     constexpr uint32_t kPiece = kLaneTreeBlock;
+    constexpr uint32_t kFeed = bounce_feed<R>(SF | SF_LANE_TREE);
+    static_assert(kFeed == 64u, "a wave takes one block of lane slots per ticket");
     __shared__ __attribute__((aligned(16))) unsigned long long tree[kLaneTreeMaxNodes];
     const RT_CONSTANT_AS BounceArgs<R> *kp =
         (const RT_CONSTANT_AS BounceArgs<R> *)__builtin_amdgcn_kernarg_segment_ptr();
     const uint32_t sub_in = blockIdx.y;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t step = gridDim.x * kPiece;
     {   // a workgroup without rays leaves before it copies anything
         uint32_t n = ro_load(args_in_kernarg_segment.in_q.count + (size_t)sub_in * kCountStride);
         if (n > args_in_kernarg_segment.in_q.cap_sub) n = args_in_kernarg_segment.in_q.cap_sub;
         if ((uint64_t)blockIdx.x * kPiece >= (uint64_t)n * 64u) return;
     }
     stage_lane_tree<R>(args_in_kernarg_segment.S, (RT_LDS_AS unsigned long long *)tree, kPiece);
-    for (uint32_t base = blockIdx.x * kPiece;; base += step) {
+    // Rays are handed out 64 lane slots at a time through a ticket counter per sub-queue (the word after its
+    // length, zero when the frame starts): a wave that finishes a short walk takes the next ticket instead of
+    // waiting for the slowest wave of a round, and a workgroup whose own sub-queue is used up goes on with its
+    // neighbours'.  Which block a ray belongs to, and so where its children go, depends on its lane slot alone.
+    const uint32_t n_sub = gridDim.y;
+    // Lane slots of a sub-queue of n rays, and the lanes each ray gets.  A short level: one ray per wave, the 64
+    // lanes side by side on the hierarchy (see k_bounce; n * 64 lane slots stay within the sub-queue's capacity
+    // in whole blocks, so the bound on the output sub-queues holds).  Between that and a level that fills the
+    // chip's lanes, one ray per 2, 4 ... lanes: a wave takes as long as the slowest of its rays, and there are
+    // wave slots to spare.
+    auto slots_of = [n_sub](uint32_t n, uint32_t cap_sub, uint32_t &spread) {
+        if (n > cap_sub) n = cap_sub;
+        const uint64_t room = ((uint64_t)cap_sub + kFeed - 1) / kFeed * kFeed;
+        constexpr uint32_t kWideBelow = (SF & SF_TRANSPARENT) ? kTreeWideRaysGlass : kTreeWideRays;
+        spread = 1u;
+        if ((uint64_t)n * n_sub <= kWideBelow && (uint64_t)n * 64u <= room) {
+            spread = 64u;
+        } else {
+            const uint32_t budget = kSpreadLanes / n_sub;
+            while (spread < 16u && (uint64_t)n * (spread * 2u) <= budget && (uint64_t)n * (spread * 2u) <= room) spread *= 2u;
+        }
+        return n * spread;
+    };
+    uint32_t sub_cur = sub_in;
+    uint32_t ahead = 0;  // sub-queues sub_in + 1 ... sub_in + ahead are known to be used up
+    uint32_t in_vain = 0;  // times a sub-queue that seemed to have lane slots left had none when asked
+    for (;;) {
         asm volatile("" : "+s"(kp));  // see k_bounce
         BounceArgs<R> A;
         __builtin_memcpy(&A, kp, sizeof A);
         A.S.q_lds = (uint32_t)(uintptr_t)(RT_LDS_AS unsigned long long *)tree;
-        uint32_t n = ro_load(A.in_q.count + (size_t)sub_in * kCountStride);
+        uint32_t *line = A.in_q.count + (size_t)sub_cur * kCountStride;
+        uint32_t n = ro_load(line);
         if (n > A.in_q.cap_sub) n = A.in_q.cap_sub;
-        // a short level: one ray per wave, the 64 lanes side by side on the hierarchy (see k_bounce; n * 64 lane
-        // slots stay within the sub-queue's capacity in whole blocks, so the bound on the output sub-queues holds)
-        const uint64_t room = ((uint64_t)A.in_q.cap_sub + kPiece - 1) / kPiece * kPiece;
-        constexpr uint32_t kWideBelow = (SF & SF_TRANSPARENT) ? kTreeWideRaysGlass : kTreeWideRays;
-        const bool wide = (uint64_t)n * gridDim.y <= kWideBelow && (uint64_t)n * 64u <= room;
-        // Between the two, a level that does not fill the chip's lanes gets one ray per 2, 4 ... lanes: a wave
-        // takes as long as the slowest of its rays, and there are wave slots to spare.
-        uint32_t spread = 1u;
-        if (wide) {
-            spread = 64u;
-        } else {
-            const uint32_t budget = kSpreadLanes / gridDim.y;
-            while (spread < 16u && (uint64_t)n * (spread * 2u) <= budget && (uint64_t)n * (spread * 2u) <= room) spread *= 2u;
+        uint32_t spread;
+        const uint32_t total = slots_of(n, A.in_q.cap_sub, spread);
+        const bool wide = spread == 64u;
+        uint32_t base = 0;
+        if (lane == 0u && total != 0u) base = atomicAdd(line + 1, kFeed);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (total == 0u || base >= total) {
+            // This sub-queue is used up.  The 64 lanes look at the 64 sub-queues after the ones already known to be
+            // used up (lengths and tickets read past the vector cache, which may hold what an earlier look saw);
+            // the wave goes on with the first that has lane slots left, or ends when none has.  Not in a level of one
+            // ray per wave, and not for ever: at the end of a level every wave would chase the last few tickets.
+            if (sub_cur != sub_in) {
+                ahead = ((sub_cur - sub_in) & (n_sub - 1u));  // it was the first with slots left: now it has none
+                if (++in_vain == kTreeStealTries) break;
+            }
+            if (total != 0u && wide) break;
+            uint32_t found = 0;
+            while (ahead + 1u < n_sub) {
+                const uint32_t dist = ahead + 1u + lane;
+                const bool in_range = dist < n_sub;
+                const uint32_t *ln = A.in_q.count + (size_t)((sub_in + dist) & (n_sub - 1u)) * kCountStride;
+                uint32_t ns = 0, tk = 0;
+                if (in_range) {
+                    ns = __hip_atomic_load(ln, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    tk = __hip_atomic_load(ln + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                uint32_t sp;
+                const uint32_t slots = slots_of(ns, A.in_q.cap_sub, sp);
+                const unsigned long long m = __ballot(in_range && tk < slots && sp != 64u);
+                if (m != 0ull) {
+                    found = ahead + 1u + (uint32_t)__builtin_ctzll(m);
+                    break;
+                }
+                ahead += 64u;
+            }
+            if (found == 0u) break;
+            ahead = found - 1u;
+            sub_cur = (sub_in + found) & (n_sub - 1u);
+            continue;
         }
-        const uint32_t total = n * spread;
-        if (base >= total) break;
-        const uint32_t lane_slot = base + threadIdx.x;
+        const uint32_t lane_slot = base + lane;
         const uint32_t k = lane_slot / spread;
         const bool valid = k < n && (lane_slot & (spread - 1u)) == 0u;
         Node<R> nd;
         nd.hit = false;
         nd.has_reflect = nd.has_refract = false;
         nd.lighting = { R(0), R(0), R(0) };
-        const uint32_t block = base / kPiece;
-        const uint32_t sub = (block + sub_in) & A.out_q.sub_mask;
+        const uint32_t block = base / kFeed;  // (a ticket is one block)
+        const uint32_t sub = (block + sub_cur) & A.out_q.sub_mask;
         R w = R(0);
         uint32_t px_index = 0;
         V3<R> ro = { R(0), R(0), R(0) }, rd = ro;
-        if (valid) entry_load<R>(A.in_q, sub_in, k, ro, rd, w, px_index);
+        if (valid) entry_load<R>(A.in_q, sub_cur, k, ro, rd, w, px_index);
         if (wide) {
             auto all = [](R v) {
                 if constexpr (sizeof(R) == 8) {
@@ -404,14 +458,13 @@ k_bounce_tree(BounceArgs<R> args_in_kernarg_segment)
                             c.under_point, c.refract_dir, w * c.refract_factor, px_index);
             });
         }
-        count_hits(A.stats, block + sub_in, A.level, valid && nd.hit);
+        count_hits(A.stats, block + sub_cur, A.level, valid && nd.hit);
         if (valid && nd.hit) {
             R *px = A.fb + (size_t)px_index * 3;
             fb_add<R>(px + 0, nd.lighting.x * w);
             fb_add<R>(px + 1, nd.lighting.y * w);
             fb_add<R>(px + 2, nd.lighting.z * w);
         }
-        if ((uint64_t)base + step >= total) break;
     }
 }
 

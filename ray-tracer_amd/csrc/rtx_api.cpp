@@ -822,7 +822,7 @@ struct FramePlan {
 // Queue sizes for chunks of `units` rows / rays.  Workgroup b of the primary kernel appends to
 // sub-queue b mod n_sub and each of its rays (one per thread) queues at most g children, which
 // bounds the level-1 sub-queues; a bounce launch feeds every output sub-queue from exactly
-// ceil(cap_sub / bounce_block) pieces, which bounds the next level the same way.
+// ceil(cap_sub / bounce_feed) blocks, which bounds the next level the same way.
 template <typename R>
 void size_queues(uint32_t sf, uint32_t levels, uint32_t hsize, uint64_t units, FramePlan *p)
 {
@@ -844,8 +844,8 @@ void size_queues(uint32_t sf, uint32_t levels, uint32_t hsize, uint64_t units, F
         uint64_t &tot = (L & 1) ? p->odd_entries : p->even_entries;
         tot = std::max(tot, cap * n_sub);
         // (an output sub-queue is fed by one block per block index of the input; a block holds at most
-        // bounce_block rays, and no more than its whole sub-queue)
-        const uint64_t piece = bounce_block<R>(sf);
+        // bounce_feed rays, and no more than its whole sub-queue)
+        const uint64_t piece = bounce_feed<R>(sf);
         cap = ((cap + piece - 1) / piece) * std::min<uint64_t>(piece, cap) * g;
     }
     p->bytes = (size_t)((p->odd_entries + p->even_entries) * 8 * sizeof(R));
