@@ -352,22 +352,16 @@ k_bounce_tree(BounceArgs<R> args_in_kernarg_segment)
     // waiting for the slowest wave of a round, and a workgroup whose own sub-queue is used up goes on with its
     // neighbours'.  Which block a ray belongs to, and so where its children go, depends on its lane slot alone.
     const uint32_t n_sub = gridDim.y;
-    // Lane slots of a sub-queue of n rays, and the lanes each ray gets.  A short level: one ray per wave, the 64
-    // lanes side by side on the hierarchy (see k_bounce; n * 64 lane slots stay within the sub-queue's capacity
-    // in whole blocks, so the bound on the output sub-queues holds).  Between that and a level that fills the
-    // chip's lanes, one ray per 2, 4 ... lanes: a wave takes as long as the slowest of its rays, and there are
-    // wave slots to spare.
+    // Lane slots of a sub-queue of n rays, and the lanes each ray gets: 64 in a short level (one ray per wave, the
+    // lanes side by side on the hierarchy, see k_bounce; n * 64 lane slots stay within the sub-queue's capacity
+    // in whole blocks, so the bound on the output sub-queues holds), otherwise one.  (Levels in between used to
+    // get one ray per 2 ... 16 lanes, as in k_bounce; with rays handed out a wave at a time full waves are
+    // faster: 3.3 against 3.6 ms on the 4K frame of 10 002 objects with glass, whose levels hold 60 000 - 90 000 rays.)
     auto slots_of = [n_sub](uint32_t n, uint32_t cap_sub, uint32_t &spread) {
         if (n > cap_sub) n = cap_sub;
         const uint64_t room = ((uint64_t)cap_sub + kFeed - 1) / kFeed * kFeed;
         constexpr uint32_t kWideBelow = (SF & SF_TRANSPARENT) ? kTreeWideRaysGlass : kTreeWideRays;
-        spread = 1u;
-        if ((uint64_t)n * n_sub <= kWideBelow && (uint64_t)n * 64u <= room) {
-            spread = 64u;
-        } else {
-            const uint32_t budget = kSpreadLanes / n_sub;
-            while (spread < 16u && (uint64_t)n * (spread * 2u) <= budget && (uint64_t)n * (spread * 2u) <= room) spread *= 2u;
-        }
+        spread = ((uint64_t)n * n_sub <= kWideBelow && (uint64_t)n * 64u <= room) ? 64u : 1u;
         return n * spread;
     };
     uint32_t sub_cur = sub_in;
