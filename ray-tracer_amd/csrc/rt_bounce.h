@@ -321,12 +321,6 @@ RT_DEV void entry_load(const QueueDev<R> &q, uint32_t sub, uint32_t idx, V3<R> &
     weight = v[6];
     pixel = pixel_bits_load<R>(v[7]);
 }
-// Below how many rays a level gets one ray per wave (measured on 4K frames of 10 002 objects: the 35 000-ray level
-// of the opaque scene takes 0.38 ms lane by lane and 0.30 ms a wave per ray, its 3 500-ray level 0.27 and 0.06 ms;
-// with 25 glass objects, whose deeper levels hold 60 000 - 90 000 rays each, the frame takes 3.5 ms with the
-// threshold at 4 096, 4.3 at 32 768 and 7.7 at 131 072: there the container walk of a wave per ray is made by 64
-// lanes that hold the same ray).
-constexpr uint32_t kTreeWideRays = 65536u, kTreeWideRaysGlass = 4096u;  // a level of at most this many rays gets one ray per wave here
 constexpr uint32_t kTreeStealTries = 4u;  // a wave ends after asking this many other sub-queues for rays in vain
 template <typename R, uint32_t SF>
 __global__ void __launch_bounds__(kLaneTreeBlock)
@@ -352,16 +346,12 @@ k_bounce_tree(BounceArgs<R> args_in_kernarg_segment)
     // waiting for the slowest wave of a round, and a workgroup whose own sub-queue is used up goes on with its
     // neighbours'.  Which block a ray belongs to, and so where its children go, depends on its lane slot alone.
     const uint32_t n_sub = gridDim.y;
-    // Lane slots of a sub-queue of n rays, and the lanes each ray gets: 64 in a short level (one ray per wave, the
-    // lanes side by side on the hierarchy, see k_bounce; n * 64 lane slots stay within the sub-queue's capacity
-    // in whole blocks, so the bound on the output sub-queues holds), otherwise one.  (Levels in between used to
-    // get one ray per 2 ... 16 lanes, as in k_bounce; with rays handed out a wave at a time full waves are
-    // faster: 3.3 against 3.6 ms on the 4K frame of 10 002 objects with glass, whose levels hold 60 000 - 90 000 rays.)
+    // Lane slots of a sub-queue of n rays, and the lanes each ray gets (tree_lanes_per_ray).  (Levels between a
+    // wave per ray and a lane per ray used to get one ray per 2 ... 16 lanes, as in k_bounce; with rays handed out
+    // a wave at a time full waves are faster: 3.3 against 3.6 ms on the 4K frame of 10 002 objects with glass.)
     auto slots_of = [n_sub](uint32_t n, uint32_t cap_sub, uint32_t &spread) {
         if (n > cap_sub) n = cap_sub;
-        const uint64_t room = ((uint64_t)cap_sub + kFeed - 1) / kFeed * kFeed;
-        constexpr uint32_t kWideBelow = (SF & SF_TRANSPARENT) ? kTreeWideRaysGlass : kTreeWideRays;
-        spread = ((uint64_t)n * n_sub <= kWideBelow && (uint64_t)n * 64u <= room) ? 64u : 1u;
+        spread = tree_lanes_per_ray(SF, n, cap_sub, n_sub);
         return n * spread;
     };
     uint32_t sub_cur = sub_in;

@@ -913,7 +913,7 @@ int enqueue_measured_levels(rtx_context *ctx, const rtx_scene *scene, Workspace 
         HIP_TRY(hipHostGetDevicePointer((void **)&ws.host_counts_dev, ws.host_counts, 0));
     }
     uint64_t cap_in = plan.cap_sub[1];
-    const uint64_t piece = bounce_block<R>(scene->sf);
+    const bool tree = (scene->sf & SF_LANE_TREE) != 0;
     std::vector<uint64_t> feed(n_sub);
     for (uint32_t L = 1; L <= max_depth; ++L) {
         uint32_t *level_counts = counts + (size_t)L * n_sub * kCountStride;
@@ -952,6 +952,9 @@ int enqueue_measured_levels(rtx_context *ctx, const rtx_scene *scene, Workspace 
         for (uint32_t y = 0; y < n_sub; ++y) {
             const uint64_t n = std::min<uint64_t>(ws.host_counts[1 + y], cap_in);
             longest = std::max(longest, n);
+            // rays per block: bounce_feed lane slots, of which k_bounce_tree gives a ray one or 64
+            const uint64_t piece = tree ? bounce_feed<R>(scene->sf) / tree_lanes_per_ray(scene->sf, (uint32_t)n, (uint32_t)cap_in, n_sub)
+                                        : bounce_feed<R>(scene->sf);
             const uint64_t full = n / piece, rest = n % piece;
             everywhere += (full / n_sub) * piece;
             add_run(y, full % n_sub, piece);
@@ -999,7 +1002,7 @@ int enqueue_measured_levels(rtx_context *ctx, const rtx_scene *scene, Workspace 
         // the launch covers the longest sub-queue that exists, not the capacity
         QueueDev<R> in_q = queue_of(L, cap_in);
         HIP_TRY(launch_bounce<R>(scene->sf, stream, scene_dev<R>(scene), in_q, queue_of(L + 1, L < max_depth ? cap_out : 0), max_depth - L, L, fb,
-                                 ws.shards, ctx->bounce_blocks, (uint32_t)longest));
+                                 ws.shards, tree ? ctx->bounce_blocks_lane : ctx->bounce_blocks, (uint32_t)longest));
         ++*launches;
         cap_in = cap_out;
     }
@@ -1026,7 +1029,9 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Workspace &ws, hipEv
     // glass frame goes from 2.06 to 2.10 ms in f64 and from 1.16 to 1.22 ms in f32).
     // The first level is planned alone, for the worst case of the primary rays.
     bool measured = false;
-    if (may_wait && !ws.fixed && children_per_hit(scene->sf) == 2 && (scene->sf & SF_CULL) == 0 && max_depth >= 2 &&
+    // (of the scenes with the sphere hierarchy only those whose bounce levels run k_bounce_tree: the host must know
+    // how the kernel deals out a sub-queue, and k_bounce's choice of lanes per ray is not repeated here)
+    if (may_wait && !ws.fixed && children_per_hit(scene->sf) == 2 && ((scene->sf & SF_CULL) == 0 || (scene->sf & SF_LANE_TREE) != 0) && max_depth >= 2 &&
         max_depth < kMaxLevels && ctx->debug_queue_divisor <= 1) {
         FramePlan whole;
         size_queues<R>(scene->sf, max_depth, W, n_units, &whole);

@@ -89,3 +89,35 @@ def test_measured_frames_in_row_chunks_and_ray_batches(rta, orc):
         s.close()
     plain.close()
     measured.close()
+
+
+def test_measured_frames_of_a_scene_with_the_sphere_hierarchy(rta):
+    """Hundreds of objects, some of glass: the bounce levels run the kernel that keeps the packed sphere hierarchy
+    in LDS and hands a sub-queue out a wave at a time, one lane or 64 lanes per ray by the level's length; the host
+    repeats that choice when it sizes the next level.  Same frame, same counters, a fraction of the memory."""
+    from ray_tracer_amd import scenes
+    W, H = 640, 360
+    w, cam = scenes.random_scene(rta.api, n_objects=600, hsize=W, vsize=H, glass_every=20)
+    flat = rta.flatten(w)
+    cd = rta.camera_desc(cam)
+    frames, stats, held = [], [], []
+    for above in (NEVER, 0):
+        ctx = rta.Context()
+        ctx.set_measured_queues(above)
+        scene = rta.Scene(ctx, flat)
+        feats = scene.features()
+        assert feats["bounding_sphere_tests"] and feats["lane_walk"] and feats["transparent"], feats
+        img, st = _render(rta, ctx, scene, cd, W, H, 5)
+        again, st2 = _render(rta, ctx, scene, cd, W, H, 5)
+        assert np.abs(img - again).max() <= 1e-12
+        assert st["rays_per_level"] == st2["rays_per_level"]
+        frames.append(img)
+        stats.append(st)
+        held.append(ctx.queue_bytes())
+        scene.close()
+        ctx.close()
+    assert np.abs(frames[0] - frames[1]).max() <= 1e-12
+    assert stats[0]["rays_per_level"] == stats[1]["rays_per_level"]
+    assert stats[0]["shadow_rays"] == stats[1]["shadow_rays"]
+    assert stats[0]["rays_per_level"][5] > 0
+    assert held[1] * 4 < held[0], held
