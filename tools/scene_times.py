@@ -48,6 +48,8 @@ def main():
         print("%-18s %s frame %8.4f ms (min %8.4f) primary %8.4f  chunks %d launches %d  %9.0f Mrays/s  queues %.2f GB  checksum %.12g" %
               (name, precision, ms, min(times), float(np.median(prim[2:])), st["n_chunks"], st["n_launches"], rays / ms / 1e3,
                ctx.queue_bytes() / 1e9, float(tile.double().sum())), flush=True)
+        if os.environ.get("RTX_SHOW_LEVELS"):
+            print("   rays per level", st["rays_per_level"], "shadow rays", st["shadow_rays"], flush=True)
         scene.close()
 
 
