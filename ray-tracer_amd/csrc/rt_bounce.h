@@ -321,7 +321,7 @@ RT_DEV void entry_load(const QueueDev<R> &q, uint32_t sub, uint32_t idx, V3<R> &
     weight = v[6];
     pixel = pixel_bits_load<R>(v[7]);
 }
-constexpr uint32_t kTreeStealTries = 4u;  // a wave ends after asking this many other sub-queues for rays in vain
+constexpr uint32_t kTreeStealTries = 4u;  // a wave ends after it has used up this many sub-queues other than its own
 template <typename R, uint32_t SF>
 __global__ void __launch_bounds__(kLaneTreeBlock)
 k_bounce_tree(BounceArgs<R> args_in_kernarg_segment)
@@ -356,7 +356,7 @@ k_bounce_tree(BounceArgs<R> args_in_kernarg_segment)
     };
     uint32_t sub_cur = sub_in;
     uint32_t ahead = 0;  // sub-queues sub_in + 1 ... sub_in + ahead are known to be used up
-    uint32_t in_vain = 0;  // times a sub-queue that seemed to have lane slots left had none when asked
+    uint32_t others = 0;  // sub-queues other than its own that this wave went on with and found used up
     for (;;) {
         asm volatile("" : "+s"(kp));  // see k_bounce
         BounceArgs<R> A;
@@ -378,7 +378,7 @@ k_bounce_tree(BounceArgs<R> args_in_kernarg_segment)
             // ray per wave, and not for ever: at the end of a level every wave would chase the last few tickets.
             if (sub_cur != sub_in) {
                 ahead = ((sub_cur - sub_in) & (n_sub - 1u));  // it was the first with slots left: now it has none
-                if (++in_vain == kTreeStealTries) break;
+                if (++others == kTreeStealTries) break;
             }
             if (total != 0u && wide) break;
             uint32_t found = 0;
