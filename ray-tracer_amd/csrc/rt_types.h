@@ -241,7 +241,8 @@ constexpr uint32_t kCountStride = 32;  // words between two counters: one 128-by
 template <typename R>
 struct QueueDev {
     R *rec;            // sub-queue q occupies entries [q * cap_sub, (q + 1) * cap_sub)
-    uint32_t *count;   // length of sub-queue q at count[q * kCountStride]
+    uint32_t *count;   // length of sub-queue q at count[q * kCountStride]; the word after it is the ticket counter of the
+                       // launch that consumes the sub-queue (lane slots handed out so far; k_bounce_tree); both zero when a frame starts
     uint32_t cap_sub;  // entries per sub-queue (0: nothing may be appended)
     uint32_t sub_mask; // n_sub - 1, n_sub a power of two
     uint32_t *overflow; // set to 1 when an append finds its sub-queue full (host memory the device can write)
