@@ -5,6 +5,8 @@
 // front of the loop at the cost of 46 vector registers; the other kernels keep that pass.
 #pragma once
 
+#include <algorithm>
+
 #include "rt_kernels.h"
 
 namespace rtx {
@@ -13,13 +15,8 @@ template <typename R> RT_DEV void fb_add(R *p, R v);
 template <> RT_DEV void fb_add<double>(double *p, double v) { unsafeAtomicAdd(p, v); }
 template <> RT_DEV void fb_add<float>(float *p, float v) { unsafeAtomicAdd(p, v); }
 
-// One recursion level.  blockIdx.y selects the input sub-queue; the gridDim.x workgroups of that
-// row read its actual length on the device and share its rays, a piece (bounce_block rays) at a time (workgroup x
-// takes blocks x, x + gridDim.x, ...): the launch has as many waves as the chip holds, whatever
-// the worst-case capacity of the queue is.  The children of block b of sub-queue y go to output
-// sub-queue (b + y) mod n_sub, so every output sub-queue is fed by at most one block per block
-// index: ceil(cap_sub / bounce_block) * bounce_block * children-per-ray entries, which is the bound
-// the host sizes the next level's cap_sub with.
+// One recursion level is one launch of one of three kernels: k_bounce_regional (scenes walked object by
+// object), k_bounce (the sphere hierarchy in memory), k_bounce_tree (its packed copy in LDS).
 // The object tables are read through constant-address-space pointers (load_uniform), which keeps
 // them in scalar registers although the loop body stores to memory.
 // Everything a bounce launch is given, as one kernel argument: the loop below reads it afresh
@@ -154,11 +151,15 @@ RT_DEV void sort_by_hit_object(QueueChunk *lds, uint32_t *hist2, uint32_t round,
 // end up with 165 vector registers; the translation unit is therefore built without
 // machine-level invariant code motion (build.sh).
 //
+// Scenes walked object by object (regional_levels()): one recursion level.  The workgroups take the blocks of
+// the queue's list in turn (kListBlock consecutive entries of one sub-queue), and the children of a ray stay in
+// the sub-queues of its screen region, reflection rays in one and refraction rays in the other.
 // Order of one round of the loop, chosen so that no memory latency is waited for:
-//   1. closest hit of this block's rays;
-//   2. (scenes walked object by object) the workgroup's rays regrouped by hit object;
-//   3. ask for the entries of the block after this one (memory -> LDS, nothing waits);
-//   4. the child rays, appended to the next level's queue at once (one atomic per wave for both
+//   1. ask for the entries of the block after this one (memory -> LDS, nothing waits) and for the list item of
+//      the block after that;
+//   2. closest hit of this block's rays;
+//   3. (f32) the workgroup's rays regrouped by hit object;
+//   4. the child rays, appended to the next level's queue at once (one instruction reserves the places of both
 //      kinds), which frees their registers for the shadow ray, whose walk covers the latency of
 //      the stores; shadow ray and lighting;
 //   5. take the next block's entries from LDS (they arrived long ago), then add this block's
@@ -166,29 +167,26 @@ RT_DEV void sort_by_hit_object(QueueChunk *lds, uint32_t *hist2, uint32_t round,
 //      computes.
 // COLD_LDS: the launch comes with cold_lds_bytes() of dynamic LDS and the scene has at most
 // kColdLdsObjects objects (launch_bounce sees to both).
-constexpr uint32_t kWideRays = 65536u;  // a level of at most this many rays gets one ray per wave (scenes with the sphere hierarchy)
 template <typename R, uint32_t SF, bool COLD_LDS>
-__global__ void __launch_bounds__(bounce_block<R>(SF))
-k_bounce(BounceArgs<R> args_in_kernarg_segment)
+__global__ void __launch_bounds__(kListBlock)
+k_bounce_regional(BounceArgs<R> args_in_kernarg_segment)
 {
-    constexpr uint32_t kPiece = bounce_block<R>(SF);  // rays per piece = threads per workgroup
-    // Scenes walked object by object (no sphere hierarchy) regroup their rays by hit object between the two
-    // phases -- in f32.  Measured on a 4K frame of an 8-object scene with glass: 46 instead of 42 of 64 lanes
-    // active per vector instruction and 3 % fewer vector instructions in either precision, which the two
-    // barriers per round give back in f64 (1.84 against 1.82 ms; rounds are twice as long there and the waves of
-    // a workgroup drift further apart) and do not in f32 (1.165 against 1.185 ms).
-    constexpr bool kSort = (SF & SF_CULL) == 0 && sizeof(R) == 4;
+    static_assert(regional_levels(SF) && bounce_block<R>(SF) == kListBlock, "a block of the list is a workgroup's piece");
+    constexpr uint32_t kPiece = kListBlock;
+    constexpr uint32_t kKinds = child_kinds(SF);
+    // The rays of a workgroup are regrouped by hit object between the two phases -- in f32.  Measured on a 4K
+    // frame of an 8-object scene with glass: 46 instead of 42 of 64 lanes active per vector instruction and 3 %
+    // fewer vector instructions in either precision, which the two barriers per round give back in f64 (1.84
+    // against 1.82 ms; rounds are twice as long there and the waves of a workgroup drift further apart) and do
+    // not in f32 (1.165 against 1.185 ms).
+    constexpr bool kSort = bounce_regroups<R>();
     constexpr bool kTrack = (SF & SF_TRANSPARENT) != 0;
     constexpr uint32_t kStride = kSliceChunks<R, kSort, kTrack>;
     __shared__ QueueChunk lds[(kPiece / 64u) * kStride * 64u];
     __shared__ uint32_t sort_hist[kSort ? 2u * kSortBins : 1u];
     const RT_CONSTANT_AS BounceArgs<R> *kp =
         (const RT_CONSTANT_AS BounceArgs<R> *)__builtin_amdgcn_kernarg_segment_ptr();
-    const uint32_t sub_in = blockIdx.y;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t step = gridDim.x * kPiece;
-    // one ray per wave for short levels of scenes with the sphere hierarchy
-    constexpr bool kWide = (SF & SF_CULL) != 0;
     if constexpr (kSort) {
         for (uint32_t i = threadIdx.x; i < 2u * kSortBins; i += kPiece) sort_hist[i] = 0u;
         if constexpr (!COLD_LDS) __syncthreads();
@@ -198,16 +196,122 @@ k_bounce(BounceArgs<R> args_in_kernarg_segment)
     V3<R> ro = { R(0), R(0), R(0) }, rd = ro;
     R weight = R(0);
     uint32_t pixel = 0;
-    bool first = true;
-    for (uint32_t base = blockIdx.x * kPiece;; base += step) {
+    // Which blocks this workgroup takes.  The list holds the blocks sub-queue by sub-queue, i.e. screen region by
+    // screen region, and the workgroups resident at one time hold consecutive indices: taken in list order they
+    // would all append to the few sub-queues of one part of the image at the same time (appends to one counter
+    // serialise).  Turn t therefore takes block (t * p) mod n_list, p a prime that does not divide n_list: a
+    // permutation of the list in which neighbours in time are far apart in the image.
+    const uint32_t n_list = ro_load(args_in_kernarg_segment.in_q.n_list);
+    if (blockIdx.x >= n_list) return;
+    const uint32_t stride_prime = n_list % 1000003u != 0u ? 1000003u : 1000033u;
+    uint32_t at_list = (uint32_t)(((unsigned long long)blockIdx.x * stride_prime) % n_list);
+    const uint32_t at_step = (uint32_t)(((unsigned long long)gridDim.x * stride_prime) % n_list);
+    auto after = [&](uint32_t at) { return at + at_step >= n_list ? at + at_step - n_list : at + at_step; };
+    using Block = typename QueueDev<R>::Block;
+    // this round's block and the next round's (the same block again where the workgroup has no more turns)
+    Block item = load_uniform(args_in_kernarg_segment.in_q.list + at_list), item1 = item;
+    at_list = after(at_list);
+    if (blockIdx.x + gridDim.x < n_list) item1 = load_uniform(args_in_kernarg_segment.in_q.list + at_list);
+    // whether this thread's entry of a block exists, and which it is
+    auto holds = [](const QueueDev<R> &q, const Block &it, uint32_t &k) {
+        uint32_t n = ro_load(q.count + (size_t)it.sub * kCountStride);
+        if (n > q.cap_sub) n = q.cap_sub;
+        k = it.block * kPiece + threadIdx.x;
+        return k < n;
+    };
+    uint32_t k;
+    bool valid = holds(args_in_kernarg_segment.in_q, item, k);
+    // the first block of this workgroup: nothing was asked for in advance
+    entry_prefetch<R>(lds, kStride, wave, valid, args_in_kernarg_segment.in_q, item.sub, k);
+    entry_take<R>(lds, kStride, wave, lane, valid, ro, rd, weight, pixel);
+    for (uint32_t ticket = blockIdx.x;; ticket += gridDim.x) {
         // the compiler must not know that kp is the same pointer as in the last round, or it
         // hoists every load from it out of the loop (some fifty scalar registers)
         asm volatile("" : "+s"(kp));
         BounceArgs<R> A;
         __builtin_memcpy(&A, kp, sizeof A);
+        const uint32_t region = item.sub / kKinds;
+        const bool more = ticket + gridDim.x < n_list;  // wave-uniform
+        uint32_t k_next = 0;
+        const bool valid_next = more && holds(A.in_q, item1, k_next);
+        if constexpr (!kSort) entry_prefetch<R>(lds, kStride, wave, valid_next, A.in_q, item1.sub, k_next);
+        at_list = after(at_list);
+        Block item2 = item1;
+        if (ticket + 2u * gridDim.x < n_list) item2 = load_uniform(A.in_q.list + at_list);
+
+        Node<R> nd;
+        nd.hit = false;
+        nd.has_reflect = nd.has_refract = false;
+        nd.lighting = { R(0), R(0), R(0) };
+        R w = weight;
+        uint32_t px_index = pixel;
+        bool live = valid;  // this thread holds a ray in the second phase (after regrouping: not the one it loaded)
+        auto push_children = [&](const Node<R> &c) {
+            queue_push_region(A.out_q, region, kKinds, c.has_reflect, c.over_point, c.reflectv, w * c.reflect_factor, c.has_refract,
+                              c.under_point, c.refract_dir, w * c.refract_factor, px_index);
+        };
+        if constexpr (kSort) {
+            Hit<R> h;
+            h.t = Num<R>::inf;
+            h.slot = h.obj = kNone;
+            h.hit_open = false;
+            h.top1 = h.top2 = kNone;
+            h.top1_t = h.top2_t = -Num<R>::inf;
+            if (valid) h = closest_hit<R, kTrack, false, (SF & SF_CHAIN) != 0, WALK_WAVE, COLD_LDS>(A.S, ro, rd, Num<R>::inf);
+            sort_by_hit_object<R, kTrack>(lds, sort_hist, round++, live, ro, rd, w, px_index, h);
+            entry_prefetch<R>(lds, kStride, wave, valid_next, A.in_q, item1.sub, k_next);
+            if (live) nd = shade_node<R, SF, false, WALK_WAVE, COLD_LDS>(A.S, ro, rd, A.remaining, h, push_children);
+        } else if (valid) {
+            nd = trace_node<R, SF, false, WALK_WAVE, COLD_LDS>(A.S, nullptr, ro, rd, A.remaining, push_children);
+        }
+        count_hits(A.stats, ticket, A.level, live && nd.hit);
+        entry_take<R>(lds, kStride, wave, lane, valid_next, ro, rd, weight, pixel);
+        if (live && nd.hit) {
+            R *px = A.fb + (size_t)px_index * 3;
+            fb_add<R>(px + 0, nd.lighting.x * w);
+            fb_add<R>(px + 1, nd.lighting.y * w);
+            fb_add<R>(px + 2, nd.lighting.z * w);
+        }
+        if (!more) break;
+        valid = valid_next;
+        item = item1;
+        item1 = item2;
+    }
+}
+
+// Scenes with the sphere hierarchy in memory: one recursion level.  blockIdx.y selects the input sub-queue; the
+// gridDim.x workgroups of that row read its actual length on the device and share its rays, a piece
+// (bounce_block rays) at a time (workgroup x takes blocks x, x + gridDim.x, ...): the launch has as many waves
+// as the chip holds, whatever the worst-case capacity of the queue is.  The children of block b of sub-queue y
+// go to output sub-queue (b + y) mod n_sub (deep levels come from few pixels, and their rays must spread over
+// the chip), so every output sub-queue is fed by at most one block per block index: ceil(cap_sub /
+// bounce_block) * bounce_block * children-per-ray entries, which is the bound the host sizes the next level's
+// cap_sub with.  The entries of the next block are asked for (memory -> LDS) before this block's are traced.
+constexpr uint32_t kWideRays = 65536u;  // a level of at most this many rays gets one ray per wave
+template <typename R, uint32_t SF>
+__global__ void __launch_bounds__(bounce_block<R>(SF))
+k_bounce(BounceArgs<R> args_in_kernarg_segment)
+{
+    static_assert((SF & SF_CULL) != 0, "scenes with the sphere hierarchy");
+    constexpr uint32_t kPiece = bounce_block<R>(SF);  // rays per piece = threads per workgroup
+    constexpr uint32_t kStride = kSliceChunks<R, false, false>;
+    __shared__ QueueChunk lds[(kPiece / 64u) * kStride * 64u];
+    const RT_CONSTANT_AS BounceArgs<R> *kp =
+        (const RT_CONSTANT_AS BounceArgs<R> *)__builtin_amdgcn_kernarg_segment_ptr();
+    const uint32_t sub_in = blockIdx.y;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t step = gridDim.x * kPiece;
+    V3<R> ro = { R(0), R(0), R(0) }, rd = ro;
+    R weight = R(0);
+    uint32_t pixel = 0;
+    bool first = true;
+    for (uint32_t base = blockIdx.x * kPiece;; base += step) {
+        asm volatile("" : "+s"(kp));  // see k_bounce_regional
+        BounceArgs<R> A;
+        __builtin_memcpy(&A, kp, sizeof A);
         uint32_t n = ro_load(A.in_q.count + (size_t)sub_in * kCountStride);
         if (n > A.in_q.cap_sub) n = A.in_q.cap_sub;
-        // With bounding-sphere tests a wave walks the union of the spheres its rays can hit, one
+        // A wave walks the union of the spheres its rays can hit, one
         // dependent fetch after another, and deep levels hold few, incoherent rays: their waves
         // are long chains on a mostly idle chip.  While a level is short enough that the whole
         // chip has lanes to spare, give every ray `spread` lanes' worth of room (one ray per
@@ -215,19 +319,15 @@ k_bounce(BounceArgs<R> args_in_kernarg_segment)
         // sub-queue's capacity rounded up to whole blocks, so the block indices, and with them
         // the bound on the output sub-queues, do not grow.
         uint32_t spread = 1u;
-        if constexpr ((SF & SF_CULL) != 0) {
-            const uint32_t budget = kSpreadLanes / gridDim.y;  // lanes per sub-queue when the chip is lightly loaded
-            const uint64_t room = ((uint64_t)A.in_q.cap_sub + kPiece - 1) / kPiece * kPiece;
-            while (spread < 64u && (uint64_t)n * (spread * 2u) <= budget && (uint64_t)n * (spread * 2u) <= room) spread *= 2u;
-            // A level of at most kWideRays rays gets a wave per ray, whose 64 lanes walk the sphere hierarchy
-            // side by side (wide_walk_table): 64 waves per SIMD at most, each some 30 steps long.
-            if constexpr (kWide) {
-                if ((uint64_t)n * gridDim.y <= kWideRays && (uint64_t)n * 64u <= room) spread = 64u;
-            }
-        }
-        const bool wide = kWide && spread == 64u;  // wave-uniform
+        const uint32_t budget = kSpreadLanes / gridDim.y;  // lanes per sub-queue when the chip is lightly loaded
+        const uint64_t room = ((uint64_t)A.in_q.cap_sub + kPiece - 1) / kPiece * kPiece;
+        while (spread < 64u && (uint64_t)n * (spread * 2u) <= budget && (uint64_t)n * (spread * 2u) <= room) spread *= 2u;
+        // A level of at most kWideRays rays gets a wave per ray, whose 64 lanes walk the sphere hierarchy
+        // side by side (wide_walk_table): 64 waves per SIMD at most, each some 30 steps long.
+        if ((uint64_t)n * gridDim.y <= kWideRays && (uint64_t)n * 64u <= room) spread = 64u;
+        const bool wide = spread == 64u;  // wave-uniform
         const uint32_t total = n * spread;  // lane slots of this sub-queue
-        if (base >= total) break;  // (the same for every wave of the workgroup: the barriers below are met by all or none)
+        if (base >= total) break;
         auto slot_of = [&](uint32_t block_base, uint32_t &k) {
             const uint32_t lane_slot = block_base + threadIdx.x;
             k = lane_slot / spread;
@@ -242,7 +342,7 @@ k_bounce(BounceArgs<R> args_in_kernarg_segment)
         }
         const bool more = base + step < total;  // wave-uniform
         const bool valid_next = more && slot_of(base + step, k_next);
-        if constexpr (!kSort) entry_prefetch<R>(lds, kStride, wave, valid_next, A.in_q, sub_in, k_next);
+        entry_prefetch<R>(lds, kStride, wave, valid_next, A.in_q, sub_in, k_next);
 
         Node<R> nd;
         nd.hit = false;
@@ -250,25 +350,9 @@ k_bounce(BounceArgs<R> args_in_kernarg_segment)
         nd.lighting = { R(0), R(0), R(0) };
         const uint32_t block = base / kPiece;
         const uint32_t sub = (block + sub_in) & A.out_q.sub_mask;
-        R w = weight;
-        uint32_t px_index = pixel;
-        bool live = valid;  // this thread holds a ray in the second phase (after regrouping: not the one it loaded)
-        auto push_children = [&](const Node<R> &c) {
-            queue_push2(A.out_q, sub, c.has_reflect, c.over_point, c.reflectv, w * c.reflect_factor, c.has_refract,
-                        c.under_point, c.refract_dir, w * c.refract_factor, px_index);
-        };
-        if constexpr (kSort) {
-            Hit<R> h;
-            h.t = Num<R>::inf;
-            h.slot = h.obj = kNone;
-            h.hit_open = false;
-            h.top1 = h.top2 = kNone;
-            h.top1_t = h.top2_t = -Num<R>::inf;
-            if (valid) h = closest_hit<R, kTrack, false, (SF & SF_CHAIN) != 0, WALK_WAVE, COLD_LDS>(A.S, ro, rd, Num<R>::inf);
-            sort_by_hit_object<R, kTrack>(lds, sort_hist, round++, live, ro, rd, w, px_index, h);
-            entry_prefetch<R>(lds, kStride, wave, valid_next, A.in_q, sub_in, k_next);
-            if (live) nd = shade_node<R, SF, false, WALK_WAVE, COLD_LDS>(A.S, ro, rd, A.remaining, h, push_children);
-        } else if (kWide && wide) {
+        const R w = weight;
+        const uint32_t px_index = pixel;
+        if (wide) {
             // the wave's one ray sits in lane 0 (the lane slots of a ray start at a multiple of 64):
             // every lane gets it, every lane computes the same node, lane 0 alone acts on it
             auto all = [](R v) {
@@ -283,17 +367,20 @@ k_bounce(BounceArgs<R> args_in_kernarg_segment)
             };
             if (__ballot(valid) != 0ull) {
                 const V3<R> o = { all(ro.x), all(ro.y), all(ro.z) }, d = { all(rd.x), all(rd.y), all(rd.z) };
-                nd = trace_node<R, SF, false, kWide ? WALK_WIDE : WALK_WAVE, COLD_LDS>(A.S, nullptr, o, d, A.remaining, [&](const Node<R> &c) {
+                nd = trace_node<R, SF, false, WALK_WIDE, false>(A.S, nullptr, o, d, A.remaining, [&](const Node<R> &c) {
                     queue_push2(A.out_q, sub, c.has_reflect && lane == 0u, c.over_point, c.reflectv, w * c.reflect_factor,
                                 c.has_refract && lane == 0u, c.under_point, c.refract_dir, w * c.refract_factor, px_index);
                 });
             }
         } else if (valid) {
-            nd = trace_node<R, SF, false, WALK_WAVE, COLD_LDS>(A.S, nullptr, ro, rd, A.remaining, push_children);
+            nd = trace_node<R, SF, false, WALK_WAVE, false>(A.S, nullptr, ro, rd, A.remaining, [&](const Node<R> &c) {
+                queue_push2(A.out_q, sub, c.has_reflect, c.over_point, c.reflectv, w * c.reflect_factor, c.has_refract,
+                            c.under_point, c.refract_dir, w * c.refract_factor, px_index);
+            });
         }
-        count_hits(A.stats, block + sub_in, A.level, live && nd.hit);
+        count_hits(A.stats, block + sub_in, A.level, valid && nd.hit);
         entry_take<R>(lds, kStride, wave, lane, valid_next, ro, rd, weight, pixel);
-        if (live && nd.hit) {
+        if (valid && nd.hit) {
             R *px = A.fb + (size_t)px_index * 3;
             fb_add<R>(px + 0, nd.lighting.x * w);
             fb_add<R>(px + 1, nd.lighting.y * w);
@@ -473,20 +560,27 @@ hipError_t launch_bounce(uint32_t sf, hipStream_t stream, const SceneDev<R> &sce
 #undef RTX_CALL
         return hipGetLastError();
     }
-    // Scenes small enough keep their shading table in LDS; only the variants without bounding-sphere
-    // tests exist in that form (a scene with those tests has at least 16 objects and usually thousands).
-    const uint32_t cold_bytes = (sf & SF_CULL) ? 0u : cold_lds_bytes<R>(scene.n);
+    if (regional_levels(sf)) {
+        // one-dimensional: the workgroups share the queue's block list; scenes small enough keep their
+        // shading table in LDS
+        if (!in_q.list || !in_q.n_list) return hipErrorInvalidValue;
+        const uint64_t most = (uint64_t)n_sub * (((longest ? longest : in_q.cap_sub) + piece - 1) / piece);
+        const dim3 flat((uint32_t)std::min<uint64_t>(std::max<uint64_t>(most, 1u), resident_blocks));
+        const uint32_t cold_bytes = cold_lds_bytes<R>(scene.n);
 #define RTX_CALL(SFV)                                                                                   \
-    if constexpr (((SFV) & (SF_REFLECTIVE | SF_TRANSPARENT)) != 0) {                                    \
-        if constexpr (((SFV) & SF_CULL) == 0) {                                                         \
-            if (cold_bytes)                                                                             \
-                hipLaunchKernelGGL((k_bounce<R, SFV | SF_PATTERN, true>), grid, dim3(piece), cold_bytes, stream, args); \
-            else                                                                                        \
-                hipLaunchKernelGGL((k_bounce<R, SFV | SF_PATTERN, false>), grid, dim3(piece), 0, stream, args); \
-        } else {                                                                                        \
-            hipLaunchKernelGGL((k_bounce<R, SFV | SF_PATTERN, false>), grid, dim3(piece), 0, stream, args); \
-        }                                                                                               \
+    if constexpr (regional_levels(SFV)) {                                                               \
+        if (cold_bytes)                                                                                 \
+            hipLaunchKernelGGL((k_bounce_regional<R, SFV | SF_PATTERN, true>), flat, dim3(piece), cold_bytes, stream, args); \
+        else                                                                                            \
+            hipLaunchKernelGGL((k_bounce_regional<R, SFV | SF_PATTERN, false>), flat, dim3(piece), 0, stream, args); \
     }
+        RTX_SF_SWITCH(sf, RTX_CALL)
+#undef RTX_CALL
+        return hipGetLastError();
+    }
+#define RTX_CALL(SFV)                                                                                   \
+    if constexpr (((SFV) & (SF_REFLECTIVE | SF_TRANSPARENT)) != 0 && ((SFV) & SF_CULL) != 0)            \
+        hipLaunchKernelGGL((k_bounce<R, SFV | SF_PATTERN>), grid, dim3(piece), 0, stream, args);
     RTX_SF_SWITCH(sf, RTX_CALL)
 #undef RTX_CALL
     return hipGetLastError();

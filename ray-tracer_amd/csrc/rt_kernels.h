@@ -19,6 +19,7 @@ template <typename R> struct Vec2T;
 template <> struct Vec2T<double> { using type = double2; };
 template <> struct Vec2T<float> { using type = float2; };
 
+RT_DEV uint32_t region_div_dev(uint32_t v, uint32_t magic) { return magic ? __umulhi(v, magic) : v; }
 RT_DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 template <typename R> RT_DEV uint32_t pixel_bits_load(R v);
@@ -78,6 +79,39 @@ RT_DEV void queue_push2(const QueueDev<R> &q, uint32_t sub, bool has1, V3<R> o1,
     if (has2) queue_store(q, sub, base + n1 + (uint32_t)__popcll(m2 & below), o2, d2, w2, pixel);
 }
 
+// The same for a regional queue (regional_levels()): the reflection rays go to the first and the refraction rays
+// to the last of the `kinds` sub-queues of screen region `region` (two sub-queues in scenes that both reflect and
+// refract, else one).  The two reservations travel in one instruction: the first lane that is here makes the one
+// for the reflection rays, the second the one for the refraction rays (a lane alone makes both).
+template <typename R>
+RT_DEV void queue_push_region(const QueueDev<R> &q, uint32_t region, uint32_t kinds, bool has1, V3<R> o1, V3<R> d1, R w1, bool has2,
+                              V3<R> o2, V3<R> d2, R w2, uint32_t pixel)
+{
+    const unsigned long long m1 = __ballot(has1), m2 = __ballot(has2);
+    if ((m1 | m2) == 0ull) return;
+    const uint32_t lane = lane_id();
+    const unsigned long long here = __ballot(true);
+    const uint32_t la = (uint32_t)__builtin_ctzll(here);
+    const unsigned long long rest = here & (here - 1ull);
+    const uint32_t lb = rest != 0ull ? (uint32_t)__builtin_ctzll(rest) : la;
+    const uint32_t sub1 = region * kinds, sub2 = sub1 + kinds - 1u;
+    const uint32_t n1 = (uint32_t)__popcll(m1), n2 = (uint32_t)__popcll(m2);
+    uint32_t *const c1 = q.count + (size_t)sub1 * kCountStride, *const c2 = q.count + (size_t)sub2 * kCountStride;
+    uint32_t got = 0u, got2 = 0u;
+    if (lb != la) {
+        if (lane == la || lane == lb) got = atomicAdd(lane == la ? c1 : c2, lane == la ? n1 : n2);
+        got2 = (uint32_t)__shfl((int)got, (int)lb);
+    } else if (lane == la) {
+        got = atomicAdd(c1, n1);
+        got2 = atomicAdd(c2, n2);
+    }
+    const uint32_t base1 = (uint32_t)__shfl((int)got, (int)la);
+    const uint32_t base2 = lb != la ? got2 : (uint32_t)__shfl((int)got2, (int)la);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (has1) queue_store(q, sub1, base1 + (uint32_t)__popcll(m1 & below), o1, d1, w1, pixel);
+    if (has2) queue_store(q, sub2, base2 + (uint32_t)__popcll(m2 & below), o2, d2, w2, pixel);
+}
+
 // Count the shaded hits of this wave: one atomic per wave that has any, spread over shards.
 RT_DEV void count_hits(StatShard *__restrict__ stats, uint32_t group, uint32_t level, bool hit)
 {
@@ -128,9 +162,13 @@ RT_DEV void primary_ray(const SceneDev<R> &S, const PrimScene<R> &P, V3<R> ro, V
     nd.hit = false;
     nd.has_reflect = nd.has_refract = false;
     nd.lighting = { R(0), R(0), R(0) };
+    // (block_id of a scene with regional levels: the screen region, or any number for a ray batch)
     const uint32_t sub = block_id & out_q.sub_mask;
     auto children = [&](const Node<R> &c) {
-        if constexpr ((SF & (SF_REFLECTIVE | SF_TRANSPARENT)) != 0)
+        if constexpr (regional_levels(SF))
+            queue_push_region(out_q, block_id & ((out_q.sub_mask + 1u) / child_kinds(SF) - 1u), child_kinds(SF), c.has_reflect, c.over_point,
+                              c.reflectv, c.reflect_factor, c.has_refract, c.under_point, c.refract_dir, c.refract_factor, k);
+        else if constexpr ((SF & (SF_REFLECTIVE | SF_TRANSPARENT)) != 0)
             queue_push2(out_q, sub, c.has_reflect, c.over_point, c.reflectv, c.reflect_factor, c.has_refract, c.under_point,
                         c.refract_dir, c.refract_factor, k);
     };
@@ -180,13 +218,16 @@ template <typename R, uint32_t SF, bool OUT8 = false, bool BANDED = false>
 __global__ void __launch_bounds__(kCamBlock<R>) __attribute__((amdgpu_waves_per_eu(camera_waves(SF))))
 k_primary_camera(CameraDev<R> cam, SceneDev<R> S, PrimScene<R> P, uint32_t local0, uint32_t n_rows,
                  uint32_t remaining, void *__restrict__ fb, QueueDev<R> out_q, StatShard *__restrict__ stats, RowMap map,
-                 uint32_t format)
+                 uint32_t format, RegionMap regions)
 {
     // a two-dimensional grid: row of pieces = blockIdx.y (a division by pieces_per_row otherwise, thirty
     // instructions in front of everything else in waves of three hundred)
     const uint32_t piece_row = blockIdx.y;
     const uint32_t piece_col = __builtin_amdgcn_readfirstlane(blockIdx.x * (kCamBlock<R> / 64) + (threadIdx.x >> 6));
-    const uint32_t block_id = blockIdx.y * gridDim.x + blockIdx.x;
+    // which sub-queue the children go to: by workgroup in turn, or by the screen region the workgroup lies in
+    uint32_t block_id = blockIdx.y * gridDim.x + blockIdx.x;
+    if constexpr (regional_levels(SF))
+        block_id = region_div_dev(blockIdx.y, regions.rows_magic) * regions.nx + region_div_dev(blockIdx.x, regions.cols_magic);
     uint32_t row, x;
     if constexpr ((SF & SF_CULL) != 0) {
         row = piece_row * 8u + ((threadIdx.x >> 3) & 7u);
@@ -290,18 +331,7 @@ k_pack8(const R *__restrict__ rgb, uint32_t n_pix, uint32_t format, uint8_t *__r
 }
 
 // ---- launchers --------------------------------------------------------------------------
-// One instantiation per combination of the feature bits that change code.
-// Scenes with groups share one general variant (reflection and refraction on, closest-hit shadow
-// rays), with and without the bounding-sphere tests.
-constexpr uint32_t sf_variant(uint32_t k)
-{
-    return k >= 16u ? (SF_REFLECTIVE | SF_TRANSPARENT | SF_CHAIN | ((k & 1u) ? SF_CULL : 0u))
-                    : ((k & 7u) | ((k & 8u) ? SF_CULL : 0u));
-}
-constexpr uint32_t sf_case(uint32_t sf)
-{
-    return (sf & SF_CHAIN) ? (16u | ((sf & SF_CULL) ? 1u : 0u)) : ((sf & 7u) | ((sf & SF_CULL) ? 8u : 0u));
-}
+// One instantiation per combination of the feature bits that change code (sf_variant, rt_launch.h).
 #ifdef RTX_ONLY_SF
 // tools builds (ISA inspection, experiments): a single kernel variant, whatever the scene asks for
 #define RTX_SF_SWITCH(sf, CALL) { CALL((RTX_ONLY_SF)); }
@@ -335,6 +365,13 @@ hipError_t Launch<R>::primary_camera(uint32_t sf, hipStream_t stream, const Came
                                      uint32_t remaining, void *fb, uint32_t format, const QueueDev<R> &out_q, StatShard *stats)
 {
     const dim3 grid(camera_blocks_per_row<R>(sf, cam.hsize), camera_piece_rows(sf, n_rows));
+    RegionMap regions = {};
+    if (regional_levels(sf)) {
+        uint32_t cols, rows;
+        region_split(grid.x, grid.y, (out_q.sub_mask + 1u) / layout_kinds(sf), &regions.nx, &cols, &rows);
+        regions.cols_magic = region_magic(cols);
+        regions.rows_magic = region_magic(rows);
+    }
     if (grid.y > 65535u) return hipErrorInvalidValue;  // plan_frame keeps chunks below that
     // the 8-bit variants exist for the scenes that can use them: those in which nothing reflects or
     // refracts; the variants that deal bands out to parts spare the plain row range their divisions
@@ -342,7 +379,7 @@ hipError_t Launch<R>::primary_camera(uint32_t sf, hipStream_t stream, const Came
     const uint32_t first = banded ? local0 : map.first + local0;  // what the kernel adds its row to
 #define RTX_LAUNCH_CAM(SFV, OUT8, BANDED)                                                                            \
     hipLaunchKernelGGL((k_primary_camera<R, SFV | SF_PATTERN, OUT8, BANDED>), grid, dim3(kCamBlock<R>), 0, \
-                       stream, cam, scene, prim, first, n_rows, remaining, fb, out_q, stats, map, format)
+                       stream, cam, scene, prim, first, n_rows, remaining, fb, out_q, stats, map, format, regions)
 #define RTX_CALL(SFV)                                                                                                \
     if constexpr (((SFV) & (SF_REFLECTIVE | SF_TRANSPARENT)) == 0) {                                               \
         if (format != 0u) { if (banded) RTX_LAUNCH_CAM(SFV, true, true); else RTX_LAUNCH_CAM(SFV, true, false); }    \

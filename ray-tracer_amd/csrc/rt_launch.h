@@ -26,6 +26,8 @@ template <typename R> constexpr uint32_t bounce_block(uint32_t sf)
     if (sf & SF_LANE_TREE) return kLaneTreeBlock;
     return sizeof(R) == 8 ? ((sf & SF_CULL) ? 128u : 256u) : 256u;
 }
+// whether the bounce kernel of regional levels regroups a workgroup's rays by hit object between walk and shading
+template <typename R> constexpr bool bounce_regroups() { return sizeof(R) == 4; }
 // Lane slots per block index of a bounce launch: the children of block b of sub-queue y go to sub-queue
 // (b + y) mod n_sub, whatever workgroup or wave traces them, which is what bounds the next level's sub-queues.
 // A block is a workgroup's piece, except in the kernel that hands its rays out a wave at a time: there a block
@@ -55,6 +57,65 @@ constexpr uint32_t tree_lanes_per_ray(uint32_t sf, uint32_t n, uint32_t cap_sub,
     const uint64_t room = ((uint64_t)cap_sub + feed - 1) / feed * feed;
     const uint32_t wide_below = (sf & SF_TRANSPARENT) ? kTreeWideRaysGlass : kTreeWideRays;
     return ((uint64_t)n * n_sub <= wide_below && (uint64_t)n * 64u <= room) ? 64u : 1u;
+}
+// One instantiation of the kernels per combination of the feature bits that change code: sf_variant(sf_case(sf))
+// is the combination a scene with feature bits sf runs as.  Scenes with groups share one general variant
+// (reflection and refraction on, closest-hit shadow rays), with and without the bounding-sphere tests.
+constexpr uint32_t sf_variant(uint32_t k)
+{
+    return k >= 16u ? (SF_REFLECTIVE | SF_TRANSPARENT | SF_CHAIN | ((k & 1u) ? SF_CULL : 0u))
+                    : ((k & 7u) | ((k & 8u) ? SF_CULL : 0u));
+}
+constexpr uint32_t sf_case(uint32_t sf)
+{
+    return (sf & SF_CHAIN) ? (16u | ((sf & SF_CULL) ? 1u : 0u)) : ((sf & 7u) | ((sf & SF_CULL) ? 8u : 0u));
+}
+// reflection and refraction: how many of the two the rays of a kernel variant can spawn (for a scene: of the
+// variant it runs as, which is what lays out its regional queues)
+constexpr uint32_t child_kinds(uint32_t sf) { return ((sf & SF_REFLECTIVE) ? 1u : 0u) + ((sf & SF_TRANSPARENT) ? 1u : 0u); }
+constexpr uint32_t layout_kinds(uint32_t scene_sf) { return child_kinds(sf_variant(sf_case(scene_sf))); }
+// Scenes walked object by object (no sphere hierarchy) keep the rays of a screen region, and of one kind, together.
+// Sub-queues come in pairs: 2r holds the reflection rays and 2r + 1 the refraction rays that descend from the
+// pixels of screen region r (a camera workgroup appends to the pair of the region it lies in, RegionMap; the
+// children of a ray stay in the pair of their parent).  The 64 rays of a wave then start in the same part of the
+// image, the same way, and mostly meet the same objects next, which is what the walk and the shading, written as
+// one branch per object and case, need.  Sub-queues then differ widely in length, so the blocks of all of them
+// are put in one list (k_list_blocks) and the workgroups of the level's launch take blocks from it in turn.
+constexpr bool regional_levels(uint32_t sf) { return (sf & SF_CULL) == 0 && (sf & (SF_REFLECTIVE | SF_TRANSPARENT)) != 0; }
+// bytes of a buffer that holds a queue of n_sub sub-queues of cap_sub entries (a multiple of 256: the next buffer
+// starts behind it); behind the rays of a regional queue lies its block list
+template <typename R> inline uint64_t queue_buffer_bytes(uint32_t sf, uint64_t cap_sub, uint32_t n_sub)
+{
+    const uint64_t entries = cap_sub * n_sub;
+    uint64_t b = entries * 8 * sizeof(R);
+    if (regional_levels(sf)) b += (entries / kListBlock + n_sub + 1u) * 8u;  // every sub-queue ends with at most one partial block
+    return (b + 255u) & ~(uint64_t)255u;
+}
+template <typename R> inline void queue_list_plane(uint32_t sf, QueueDev<R> &q)
+{
+    q.list = nullptr;
+    q.n_list = nullptr;
+    if (regional_levels(sf) && q.rec) {
+        q.list = reinterpret_cast<typename QueueDev<R>::Block *>(q.rec + (uint64_t)q.cap_sub * (q.sub_mask + 1u) * 8);
+        q.n_list = q.count + 2;  // a spare word of the first sub-queue's counter line
+    }
+}
+// Screen regions of a camera launch of grid_x x grid_y workgroups: workgroup (bx, by) lies in region
+// (by / rows) * nx + bx / cols, the quotients taken as (v * magic) >> 32 (exact for v, divisor < 65536).
+struct RegionMap {
+    uint32_t cols_magic, rows_magic, nx, pad;
+};
+inline uint32_t region_magic(uint32_t d) { return d <= 1u ? 0u : (uint32_t)((((uint64_t)1 << 32) + d - 1u) / d); }  // 0: the divisor is 1
+// n_regions (a power of two) regions for a grid: nx x ny of them, each cols x rows workgroups, about square in
+// pixels (a workgroup is 64 pixels wide and one high)
+inline void region_split(uint32_t grid_x, uint64_t grid_y, uint32_t n_regions, uint32_t *nx, uint32_t *cols, uint32_t *rows)
+{
+    uint32_t x = 1;
+    while (x < n_regions && (uint64_t)x * x * grid_y < (uint64_t)n_regions * grid_x * 64u && x * 2u <= grid_x) x *= 2u;
+    const uint32_t y = n_regions / x;
+    *nx = x;
+    *cols = (grid_x + x - 1u) / x;
+    *rows = (uint32_t)((grid_y + y - 1u) / y);
 }
 // Threads per workgroup of the camera kernel.  Its waves share nothing.  In f64 one wave per
 // workgroup: single waves fill the chip's last round more evenly than groups of four (4K headline
@@ -130,6 +191,14 @@ constexpr size_t kScratchBytes = (size_t)256 << 20;
 hipError_t scratch_address(void **ptr, size_t *bytes);
 // sub-queue lengths into host memory the device can write, then a sequence number (scratch.hip)
 hipError_t launch_publish_counts(hipStream_t stream, const uint32_t *counts, uint32_t n_sub, uint32_t stride, uint32_t *host, uint32_t seq);
+
+// the block list of a regional queue (scratch.hip); nothing to do for other queues
+hipError_t list_blocks_launch(hipStream_t stream, const uint32_t *count, uint32_t n_sub, uint32_t cap_sub, void *list, uint32_t *n_list);
+template <typename R> inline hipError_t launch_list_blocks(hipStream_t stream, const QueueDev<R> &q)
+{
+    if (!q.list || q.cap_sub == 0u) return hipSuccess;
+    return list_blocks_launch(stream, q.count, q.sub_mask + 1u, q.cap_sub, q.list, q.n_list);
+}
 
 // f64 only: intermediate results of one color_at node per ray.
 hipError_t launch_probe(uint32_t sf, uint32_t grid, hipStream_t stream, const SceneDev<double> &scene,

@@ -246,7 +246,16 @@ struct QueueDev {
     uint32_t cap_sub;  // entries per sub-queue (0: nothing may be appended)
     uint32_t sub_mask; // n_sub - 1, n_sub a power of two
     uint32_t *overflow; // set to 1 when an append finds its sub-queue full (host memory the device can write)
+    // Queues of scenes whose levels keep the rays of a screen region together (regional_levels(), rt_launch.h;
+    // null otherwise): the blocks of kListBlock entries of all sub-queues ({sub-queue, block within it},
+    // *n_list of them, written by k_list_blocks between the producer and the consumer), from which the
+    // workgroups of the consuming launch take their work in turn.
+    struct Block { uint32_t sub, block; };
+    Block *list;
+    uint32_t *n_list;
 };
+constexpr uint32_t kListBlock = 256;   // entries per block of the list (= threads of the consuming workgroup)
+constexpr uint32_t kListMaxSub = 2048; // most sub-queues of such a queue
 
 // Per-level counters, one block of shards per render call (summed on the host).
 // lanes of a lightly loaded chip: 1024 SIMDs x 4 waves x 64 (k_bounce spreads short levels over them)

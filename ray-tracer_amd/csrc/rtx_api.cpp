@@ -815,7 +815,7 @@ struct FramePlan {
     uint32_t n_sub = 1;         // sub-queues per queue (power of two)
     uint64_t chunk_units = 0;   // rows (camera renders) or rays (batches) per chunk
     uint64_t cap_sub[kMaxLevels + 2] = {};  // entries per sub-queue of the queue that feeds level L
-    uint64_t odd_entries = 0, even_entries = 0;  // entries of the two ping-pong buffers
+    uint64_t odd_bytes = 0, even_bytes = 0;  // the two ping-pong buffers
     size_t bytes = 0;
 };
 
@@ -823,32 +823,54 @@ struct FramePlan {
 // sub-queue b mod n_sub and each of its rays (one per thread) queues at most g children, which
 // bounds the level-1 sub-queues; a bounce launch feeds every output sub-queue from exactly
 // ceil(cap_sub / bounce_feed) blocks, which bounds the next level the same way.
+// Scenes with regional levels: a camera workgroup appends to the sub-queues of its screen region, one per
+// kind of child, each of which holds at most one ray per pixel of the region; the children of a ray stay
+// in the sub-queues of its region, so a sub-queue of the next level holds at most what all sub-queues of
+// the region hold now.
 template <typename R>
 void size_queues(uint32_t sf, uint32_t levels, uint32_t hsize, uint64_t units, FramePlan *p)
 {
     const uint64_t g = children_per_hit(sf);
+    const bool regional = regional_levels(sf);
     const uint64_t blocks0 = hsize ? camera_blocks<R>(sf, hsize, units) : (units + kRayBlock<R> - 1) / kRayBlock<R>;
     uint32_t n_sub = 1;
-    while (n_sub < 256 && (uint64_t)n_sub * 2 * 8 <= blocks0) n_sub *= 2;
+    const uint32_t most_sub = regional ? kListMaxSub : 256u;
+    while (n_sub < most_sub && (uint64_t)n_sub * 2 * 8 <= blocks0) n_sub *= 2;
+    const uint32_t kinds = layout_kinds(sf);  // sub-queues per region: one per kind of child the kernels can queue
+    if (regional && n_sub < kinds) n_sub = kinds;
     p->levels = levels;
     p->n_sub = n_sub;
     p->chunk_units = units;
-    p->odd_entries = p->even_entries = 0;
+    p->odd_bytes = p->even_bytes = 0;
     for (auto &c : p->cap_sub) c = 0;
     // rays per primary workgroup: kRayBlock of a ray batch, kCamBlock pixels of a frame, of whose
     // 8x8 tiles only `units` rows exist when the chunk is lower than a tile
     const uint64_t per_block0 = !hsize ? (uint64_t)kRayBlock<R> : ((sf & SF_CULL) && units < 8) ? (kCamBlock<R> / 8) * units : (uint64_t)kCamBlock<R>;
     uint64_t cap = ((blocks0 + n_sub - 1) / n_sub) * per_block0 * g;
+    if (regional) {
+        const uint32_t n_regions = n_sub / kinds;
+        if (hsize) {
+            uint32_t nx, cols, rows;
+            region_split(camera_blocks_per_row<R>(sf, hsize), camera_piece_rows(sf, units), n_regions, &nx, &cols, &rows);
+            cap = (uint64_t)cols * rows * per_block0;
+        } else {
+            cap = ((blocks0 + n_regions - 1) / n_regions) * per_block0;  // workgroup b of a ray batch: region b mod n_regions
+        }
+    }
     for (uint32_t L = 1; L <= levels; ++L) {
         p->cap_sub[L] = cap;
-        uint64_t &tot = (L & 1) ? p->odd_entries : p->even_entries;
-        tot = std::max(tot, cap * n_sub);
-        // (an output sub-queue is fed by one block per block index of the input; a block holds at most
-        // bounce_feed rays, and no more than its whole sub-queue)
-        const uint64_t piece = bounce_feed<R>(sf);
-        cap = ((cap + piece - 1) / piece) * std::min<uint64_t>(piece, cap) * g;
+        uint64_t &tot = (L & 1) ? p->odd_bytes : p->even_bytes;
+        tot = std::max(tot, queue_buffer_bytes<R>(sf, cap, n_sub));
+        if (regional) {
+            cap *= kinds;
+        } else {
+            // (an output sub-queue is fed by one block per block index of the input; a block holds at most
+            // bounce_feed rays, and no more than its whole sub-queue)
+            const uint64_t piece = bounce_feed<R>(sf);
+            cap = ((cap + piece - 1) / piece) * std::min<uint64_t>(piece, cap) * g;
+        }
     }
-    p->bytes = (size_t)((p->odd_entries + p->even_entries) * 8 * sizeof(R));
+    p->bytes = (size_t)(p->odd_bytes + p->even_bytes);
 }
 
 // Split the frame into chunks of whole rows (or of rays, hsize = 0) so that both ping-pong
@@ -906,8 +928,9 @@ int enqueue_measured_levels(rtx_context *ctx, const rtx_scene *scene, Workspace 
 {
     const uint32_t n_sub = plan.n_sub;
     const uint64_t g = children_per_hit(scene->sf);
+    const bool regional = regional_levels(scene->sf);  // the children of a ray stay in the sub-queues of its region
     if (!ws.host_counts) {
-        HIP_TRY(hipHostMalloc((void **)&ws.host_counts, 512 * sizeof(uint32_t), hipHostMallocMapped));
+        HIP_TRY(hipHostMalloc((void **)&ws.host_counts, (kListMaxSub + 64) * sizeof(uint32_t), hipHostMallocMapped));
         ws.host_counts[0] = 0u;
         ws.publish_seq = 0u;
         HIP_TRY(hipHostGetDevicePointer((void **)&ws.host_counts_dev, ws.host_counts, 0));
@@ -932,7 +955,7 @@ int enqueue_measured_levels(rtx_context *ctx, const rtx_scene *scene, Workspace 
                 if (q != hipErrorNotReady) return fail(RTX_ERR_DEVICE, "waiting for level %u: %s", L, hipGetErrorString(q));
             }
         }
-        uint64_t longest = 0, cap_out = 0;
+        uint64_t longest = 0, cap_out = 0, running_region = 0, cap_region = 0;
         // feed[s]: rays the blocks that send to output sub-queue s hold.  Sub-queue y sends its block b
         // to (b + y) mod n_sub: every full turn of n_sub blocks adds a block to each s, the blocks
         // left over go to a run of sub-queues that starts at y (kept as differences, summed below).
@@ -952,6 +975,12 @@ int enqueue_measured_levels(rtx_context *ctx, const rtx_scene *scene, Workspace 
         for (uint32_t y = 0; y < n_sub; ++y) {
             const uint64_t n = std::min<uint64_t>(ws.host_counts[1 + y], cap_in);
             longest = std::max(longest, n);
+            if (regional) {  // what the sub-queues of this one's region hold together
+                if (y % layout_kinds(scene->sf) == 0) running_region = 0;
+                running_region += n;
+                cap_region = std::max(cap_region, running_region);
+                continue;
+            }
             // rays per block: bounce_feed lane slots, of which k_bounce_tree gives a ray one or 64
             const uint64_t piece = tree ? bounce_feed<R>(scene->sf) / tree_lanes_per_ray(scene->sf, (uint32_t)n, (uint32_t)cap_in, n_sub)
                                         : bounce_feed<R>(scene->sf);
@@ -968,10 +997,11 @@ int enqueue_measured_levels(rtx_context *ctx, const rtx_scene *scene, Workspace 
         if (longest == 0) break;
         if (L < max_depth) {
             for (uint64_t f : feed) cap_out = std::max(cap_out, f);
+            if (regional) cap_out = cap_region;
             if (cap_out > 0x7fffff00ull) return fail(RTX_ERR_INVALID, "level %u of this frame has too many rays for one launch; render fewer rows per call", L + 1);
             void **buf = ((L + 1) & 1) ? &ws.queues : &ws.queues_even;
             size_t *have = ((L + 1) & 1) ? &ws.queue_bytes : &ws.queue_even_bytes;
-            const size_t need = (size_t)(cap_out * n_sub * 8 * sizeof(R));
+            const size_t need = (size_t)queue_buffer_bytes<R>(scene->sf, cap_out, n_sub);
             if (need > *have) {
                 // the buffer holds the queue this level's input was made from: nothing reads it any more
                 if (*buf) HIP_TRY(hipFree(*buf));
@@ -997,13 +1027,16 @@ int enqueue_measured_levels(rtx_context *ctx, const rtx_scene *scene, Workspace 
             q.cap_sub = (uint32_t)cap;
             q.sub_mask = n_sub - 1;
             q.overflow = ctx->overflow_dev;
+            queue_list_plane<R>(scene->sf, q);
             return q;
         };
         // the launch covers the longest sub-queue that exists, not the capacity
         QueueDev<R> in_q = queue_of(L, cap_in);
-        HIP_TRY(launch_bounce<R>(scene->sf, stream, scene_dev<R>(scene), in_q, queue_of(L + 1, L < max_depth ? cap_out : 0), max_depth - L, L, fb,
+        const QueueDev<R> out_q = queue_of(L + 1, L < max_depth ? cap_out : 0);
+        HIP_TRY(launch_bounce<R>(scene->sf, stream, scene_dev<R>(scene), in_q, out_q, max_depth - L, L, fb,
                                  ws.shards, tree ? ctx->bounce_blocks_lane : ctx->bounce_blocks, (uint32_t)longest));
         ++*launches;
+        if (L < max_depth) HIP_TRY(launch_list_blocks<R>(stream, out_q));
         cap_in = cap_out;
     }
     return RTX_OK;
@@ -1041,8 +1074,8 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Workspace &ws, hipEv
     if (rc) return rc;
     if (measured) {
         plan.levels = max_depth;
-        plan.even_entries = 0;
-        plan.bytes = (size_t)(plan.odd_entries * 8 * sizeof(R));
+        plan.even_bytes = 0;
+        plan.bytes = (size_t)plan.odd_bytes;
     }
     if (!ws.fixed && plan.bytes > ws.queue_bytes) {
         // Not enough memory for the queues as planned: first take back what idle slots hold, then
@@ -1069,8 +1102,8 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Workspace &ws, hipEv
             if (rc) return rc;
             if (measured) {
                 plan.levels = max_depth;
-                plan.even_entries = 0;
-                plan.bytes = (size_t)(plan.odd_entries * 8 * sizeof(R));
+                plan.even_bytes = 0;
+                plan.bytes = (size_t)plan.odd_bytes;
             }
         }
     }
@@ -1165,7 +1198,7 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Workspace &ws, hipEv
     }
 
     R *q_odd = (R *)ws.queues;
-    R *q_even = q_odd + plan.odd_entries * 8;
+    R *q_even = (R *)((char *)q_odd + plan.odd_bytes);
     const SceneDev<R> &S = scene_dev<R>(scene);
     uint32_t launches = 0;
     uint64_t done = 0;
@@ -1181,6 +1214,7 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Workspace &ws, hipEv
             q.cap_sub = level <= plan.levels ? (uint32_t)plan.cap_sub[level] : 0u;
             q.sub_mask = plan.n_sub - 1;
             q.overflow = ctx->overflow_dev;
+            queue_list_plane<R>(scene->sf, q);
             return q;
         };
         const uint64_t k0 = cam ? u0 * W : u0;  // first primary ray of the chunk
@@ -1196,6 +1230,7 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Workspace &ws, hipEv
         }
         if (timed && c == 0) HIP_TRY(hipEventRecord(ev[3], stream));
         ++launches;
+        if (plan.levels >= 1u) HIP_TRY(launch_list_blocks<R>(stream, queue_at(1)));
         if (measured) {
             rc = enqueue_measured_levels<R>(ctx, scene, ws, stream, plan, counts, max_depth, fb, &launches);
             if (rc) return rc;
@@ -1210,6 +1245,7 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Workspace &ws, hipEv
                                                                 : (scene->sf & SF_CULL) ? ctx->bounce_blocks_cull : ctx->bounce_blocks,
                                      0u));
             ++launches;
+            if (L < plan.levels) HIP_TRY(launch_list_blocks<R>(stream, queue_at(L + 1)));
         }
         done += cam ? units * W : units;
         if (progress) {

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include "rt_launch.h"
+#include "rt_types.h"
 
 namespace rtx {
 
@@ -39,6 +40,59 @@ k_publish_counts(const uint32_t *__restrict__ counts, uint32_t n_sub, uint32_t s
 hipError_t launch_publish_counts(hipStream_t stream, const uint32_t *counts, uint32_t n_sub, uint32_t stride, uint32_t *host, uint32_t seq)
 {
     hipLaunchKernelGGL(k_publish_counts, dim3(1), dim3(256), 0, stream, counts, n_sub, stride, host, seq);
+    return hipGetLastError();
+}
+
+
+// The block list of a regional queue: {sub-queue, block} for every block of kListBlock entries that holds a ray,
+// sub-queue by sub-queue, and their number.  Every workgroup scans the lengths of the n_sub <= kListMaxSub
+// sub-queues for itself (a thread takes a run of consecutive sub-queues) and then writes its share of the list.
+constexpr uint32_t kListThreads = 256;
+__global__ void __launch_bounds__(kListThreads)
+k_list_blocks(const uint32_t *__restrict__ count, uint32_t n_sub, uint32_t cap_sub, QueueDev<float>::Block *__restrict__ list,
+              uint32_t *__restrict__ n_list)
+{
+    __shared__ uint32_t before[kListMaxSub + 1];  // before[q]: blocks of the sub-queues 0..q-1
+    __shared__ uint32_t of_wave[kListThreads / 64u];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t per = (n_sub + kListThreads - 1u) / kListThreads;
+    const uint32_t q0 = threadIdx.x * per;
+    uint32_t mine = 0u;
+    for (uint32_t q = q0; q < q0 + per && q < n_sub; ++q) {
+        uint32_t n = count[(size_t)q * kCountStride];
+        if (n > cap_sub) n = cap_sub;
+        mine += (n + kListBlock - 1u) / kListBlock;
+        before[q + 1u] = mine;  // within this thread's run for now
+    }
+    uint32_t incl = mine;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
+        if ((int)lane >= off) incl += up;
+    }
+    if (lane == 63u) of_wave[wave] = incl;
+    __syncthreads();
+    for (uint32_t w = 0; w < wave; ++w) incl += of_wave[w];
+    const uint32_t ahead = incl - mine;  // blocks of the sub-queues before this thread's run
+    for (uint32_t q = q0; q < q0 + per && q < n_sub; ++q) before[q + 1u] += ahead;
+    if (threadIdx.x == 0u) before[0] = 0u;
+    __syncthreads();
+    const uint32_t total = before[n_sub];
+    if (blockIdx.x == 0u && threadIdx.x == 0u) *n_list = total;
+    for (uint32_t i = blockIdx.x * kListThreads + threadIdx.x; i < total; i += gridDim.x * kListThreads) {
+        uint32_t lo = 0u, hi = n_sub;  // the last q with before[q] <= i
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (before[mid] <= i) lo = mid; else hi = mid;
+        }
+        list[i] = QueueDev<float>::Block{ lo, i - before[lo] };
+    }
+}
+hipError_t list_blocks_launch(hipStream_t stream, const uint32_t *count, uint32_t n_sub, uint32_t cap_sub, void *list, uint32_t *n_list)
+{
+    if (n_sub > kListMaxSub) return hipErrorInvalidValue;
+    // enough workgroups that a thread writes a handful of entries in a 4K frame (some 20 000 blocks per level)
+    hipLaunchKernelGGL(k_list_blocks, dim3(32), dim3(kListThreads), 0, stream, count, n_sub, cap_sub,
+                       static_cast<QueueDev<float>::Block *>(list), n_list);
     return hipGetLastError();
 }
 
