@@ -407,9 +407,12 @@ def main():
             k_ms = float(np.mean(k_primary))
             flops_launch = flops_part
         else:
-            # the dominant kernel is k_bounce, one launch per recursion level: its own algorithmic flops
-            # (everything below the primary rays) over its own time, per launch
-            roof_kernel, launches = "k_bounce", st["n_launches"] - 1
+            # the dominant kernel is the bounce kernel, one launch per recursion level: its own algorithmic flops
+            # (everything below the primary rays) over its own time, per launch (the time between the levels'
+            # events, which in scenes with regional levels includes the 5-9 us k_list_blocks launch of each level)
+            feats = scene.features()
+            roof_kernel = "k_bounce_tree" if feats["lane_walk"] else "k_bounce" if culled else "k_bounce_regional"
+            launches = st["n_launches"] - 1
             k_ms = float(np.mean(k_levels)) / launches
             flops_launch = bounce_flops(flat["shape_type"], n_pix_part, st, primary_hits) / launches
         achieved = flops_launch / (k_ms * 1e-3) / 1e12

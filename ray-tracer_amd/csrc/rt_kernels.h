@@ -222,12 +222,15 @@ k_primary_camera(CameraDev<R> cam, SceneDev<R> S, PrimScene<R> P, uint32_t local
 {
     // a two-dimensional grid: row of pieces = blockIdx.y (a division by pieces_per_row otherwise, thirty
     // instructions in front of everything else in waves of three hundred)
-    const uint32_t piece_row = blockIdx.y;
+    uint32_t piece_row = blockIdx.y;
     const uint32_t piece_col = __builtin_amdgcn_readfirstlane(blockIdx.x * (kCamBlock<R> / 64) + (threadIdx.x >> 6));
     // which sub-queue the children go to: by workgroup in turn, or by the screen region the workgroup lies in
     uint32_t block_id = blockIdx.y * gridDim.x + blockIdx.x;
-    if constexpr (regional_levels(SF))
-        block_id = region_div_dev(blockIdx.y, regions.rows_magic) * regions.nx + region_div_dev(blockIdx.x, regions.cols_magic);
+    if constexpr (regional_levels(SF)) {
+        const uint32_t region_row = blockIdx.y & ((1u << regions.ny_shift) - 1u);
+        piece_row = region_row * regions.rows + (blockIdx.y >> regions.ny_shift);
+        block_id = region_row * regions.nx + region_div_dev(blockIdx.x, regions.cols_magic);
+    }
     uint32_t row, x;
     if constexpr ((SF & SF_CULL) != 0) {
         row = piece_row * 8u + ((threadIdx.x >> 3) & 7u);
@@ -364,13 +367,16 @@ hipError_t Launch<R>::primary_camera(uint32_t sf, hipStream_t stream, const Came
                                      const PrimScene<R> &prim, const RowMap &map, uint32_t local0, uint32_t n_rows,
                                      uint32_t remaining, void *fb, uint32_t format, const QueueDev<R> &out_q, StatShard *stats)
 {
-    const dim3 grid(camera_blocks_per_row<R>(sf, cam.hsize), camera_piece_rows(sf, n_rows));
+    dim3 grid(camera_blocks_per_row<R>(sf, cam.hsize), camera_piece_rows(sf, n_rows));
     RegionMap regions = {};
     if (regional_levels(sf)) {
-        uint32_t cols, rows;
-        region_split(grid.x, grid.y, (out_q.sub_mask + 1u) / layout_kinds(sf), &regions.nx, &cols, &rows);
+        const uint32_t n_regions = (out_q.sub_mask + 1u) / layout_kinds(sf);
+        uint32_t cols;
+        region_split(grid.x, grid.y, n_regions, &regions.nx, &cols, &regions.rows);
         regions.cols_magic = region_magic(cols);
-        regions.rows_magic = region_magic(rows);
+        const uint32_t ny = n_regions / regions.nx;
+        while ((1u << regions.ny_shift) < ny) ++regions.ny_shift;
+        grid.y = ny * regions.rows;  // (at most ny - 1 rows more than the frame has)
     }
     if (grid.y > 65535u) return hipErrorInvalidValue;  // plan_frame keeps chunks below that
     // the 8-bit variants exist for the scenes that can use them: those in which nothing reflects or

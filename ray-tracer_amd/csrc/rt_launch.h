@@ -100,12 +100,16 @@ template <typename R> inline void queue_list_plane(uint32_t sf, QueueDev<R> &q)
         q.n_list = q.count + 2;  // a spare word of the first sub-queue's counter line
     }
 }
-// Screen regions of a camera launch of grid_x x grid_y workgroups: workgroup (bx, by) lies in region
-// (by / rows) * nx + bx / cols, the quotients taken as (v * magic) >> 32 (exact for v, divisor < 65536).
+// Screen regions of a camera launch: nx x ny of them (powers of two), each `cols` workgroups wide and `rows`
+// pixel rows high.  Row of workgroups `by` of the grid renders local row (by mod ny) * rows + by / ny: the
+// workgroups resident at one time then lie in all ny rows of regions instead of one or two, and their
+// appends go to as many counters (appends to one counter serialise).  The grid has ny * rows rows; those past
+// the frame have nothing to do.  Workgroup bx of a row lies in region column bx / cols, taken as
+// (bx * cols_magic) >> 32 (exact for bx, cols < 65536; cols_magic 0: cols is 1).
 struct RegionMap {
-    uint32_t cols_magic, rows_magic, nx, pad;
+    uint32_t cols_magic, nx, ny_shift, rows;
 };
-inline uint32_t region_magic(uint32_t d) { return d <= 1u ? 0u : (uint32_t)((((uint64_t)1 << 32) + d - 1u) / d); }  // 0: the divisor is 1
+inline uint32_t region_magic(uint32_t d) { return d <= 1u ? 0u : (uint32_t)((((uint64_t)1 << 32) + d - 1u) / d); }
 // n_regions (a power of two) regions for a grid: nx x ny of them, each cols x rows workgroups, about square in
 // pixels (a workgroup is 64 pixels wide and one high)
 inline void region_split(uint32_t grid_x, uint64_t grid_y, uint32_t n_regions, uint32_t *nx, uint32_t *cols, uint32_t *rows)
@@ -139,7 +143,7 @@ template <typename R> inline uint32_t camera_blocks_per_row(uint32_t sf, uint32_
 {
     return (camera_pieces_per_row(sf, hsize) + kCamBlock<R> / 64 - 1) / (kCamBlock<R> / 64);
 }
-constexpr uint64_t kCameraMaxRows = 65535u;  // rows of one camera launch (of 8x8 tiles even more would do)
+constexpr uint64_t kCameraMaxRows = 65535u - 1024u;  // rows of one camera launch: its grid numbers at most 65 535, of which a launch with screen regions leaves up to one per row of regions unused (of 8x8 tiles even more would do)
 template <typename R> inline uint64_t camera_blocks(uint32_t sf, uint32_t hsize, uint64_t n_rows)
 {
     return (uint64_t)camera_blocks_per_row<R>(sf, hsize) * camera_piece_rows(sf, n_rows);

@@ -69,5 +69,5 @@ def test_gpus_2_on_fewer_gpus_fails_and_the_rehearsal_reports_2():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["config"]["workload"].startswith("glass scene")
-    assert line["roofline"]["kernel"] == "k_bounce" and line["roofline"]["launches_per_frame"] == 5
+    assert line["roofline"]["kernel"] == "k_bounce_regional" and line["roofline"]["launches_per_frame"] == 5
     assert 0 < line["roofline"]["frac"] < 1
