@@ -35,13 +35,13 @@ struct BounceArgs {
 // asks for entry idx of sub-queue `sub` for every lane with `want` set; the entry goes from memory
 // straight into the first chunks of the wave's slice (global_load_lds: no vector registers are
 // held while it is in flight), 16 bytes per lane and instruction.
-template <typename R>
+template <typename R, bool REGIONAL = false>
 RT_DEV void entry_prefetch(QueueChunk *lds, uint32_t stride, uint32_t wave, bool want, const QueueDev<R> &q, uint32_t sub, uint32_t idx)
 {
     if (want) {
         const QueueChunk *src = reinterpret_cast<const QueueChunk *>(q.rec);
         for (uint32_t j = 0; j < kEntryChunks<R>; ++j)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + chunk_index(q, j, sub, idx)),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + chunk_index<R, REGIONAL>(q, j, sub, idx)),
                                              (__attribute__((address_space(3))) void *)(lds + (wave * stride + j) * 64u), 16, 0, 0);
     }
 }
@@ -215,14 +215,15 @@ k_bounce_regional(BounceArgs<R> args_in_kernarg_segment)
     // whether this thread's entry of a block exists, and which it is
     auto holds = [](const QueueDev<R> &q, const Block &it, uint32_t &k) {
         uint32_t n = ro_load(q.count + (size_t)it.sub * kCountStride);
-        if (n > q.cap_sub) n = q.cap_sub;
+        const uint32_t cap = sub_capacity<R, true>(q, it.sub);
+        if (n > cap) n = cap;
         k = it.block * kPiece + threadIdx.x;
         return k < n;
     };
     uint32_t k;
     bool valid = holds(args_in_kernarg_segment.in_q, item, k);
     // the first block of this workgroup: nothing was asked for in advance
-    entry_prefetch<R>(lds, kStride, wave, valid, args_in_kernarg_segment.in_q, item.sub, k);
+    entry_prefetch<R, true>(lds, kStride, wave, valid, args_in_kernarg_segment.in_q, item.sub, k);
     entry_take<R>(lds, kStride, wave, lane, valid, ro, rd, weight, pixel);
     for (uint32_t ticket = blockIdx.x;; ticket += gridDim.x) {
         // the compiler must not know that kp is the same pointer as in the last round, or it
@@ -234,7 +235,7 @@ k_bounce_regional(BounceArgs<R> args_in_kernarg_segment)
         const bool more = ticket + gridDim.x < n_list;  // wave-uniform
         uint32_t k_next = 0;
         const bool valid_next = more && holds(A.in_q, item1, k_next);
-        if constexpr (!kSort) entry_prefetch<R>(lds, kStride, wave, valid_next, A.in_q, item1.sub, k_next);
+        if constexpr (!kSort) entry_prefetch<R, true>(lds, kStride, wave, valid_next, A.in_q, item1.sub, k_next);
         at_list = after(at_list);
         Block item2 = item1;
         if (ticket + 2u * gridDim.x < n_list) item2 = load_uniform(A.in_q.list + at_list);
@@ -259,7 +260,7 @@ k_bounce_regional(BounceArgs<R> args_in_kernarg_segment)
             h.top1_t = h.top2_t = -Num<R>::inf;
             if (valid) h = closest_hit<R, kTrack, false, (SF & SF_CHAIN) != 0, WALK_WAVE, COLD_LDS>(A.S, ro, rd, Num<R>::inf);
             sort_by_hit_object<R, kTrack>(lds, sort_hist, round++, live, ro, rd, w, px_index, h);
-            entry_prefetch<R>(lds, kStride, wave, valid_next, A.in_q, item1.sub, k_next);
+            entry_prefetch<R, true>(lds, kStride, wave, valid_next, A.in_q, item1.sub, k_next);
             if (live) nd = shade_node<R, SF, false, WALK_WAVE, COLD_LDS>(A.S, ro, rd, A.remaining, h, push_children);
         } else if (valid) {
             nd = trace_node<R, SF, false, WALK_WAVE, COLD_LDS>(A.S, nullptr, ro, rd, A.remaining, push_children);

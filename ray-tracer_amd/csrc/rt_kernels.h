@@ -39,19 +39,33 @@ struct alignas(16) QueueChunk {
     uint32_t w[4];
 };
 template <typename R> constexpr uint32_t kEntryChunks = 8 * sizeof(R) / 16;
-template <typename R> RT_DEV size_t chunk_index(const QueueDev<R> &q, uint32_t j, uint32_t sub, uint32_t idx)
+// REGIONAL: a queue of a scene with regional levels, whose sub-queues may differ in capacity (QueueDev::var);
+// `sub` is then wave-uniform and the two words come through the scalar cache
+template <typename R, bool REGIONAL = false> RT_DEV size_t chunk_index(const QueueDev<R> &q, uint32_t j, uint32_t sub, uint32_t idx)
 {
-    return ((size_t)j * (q.sub_mask + 1u) + sub) * q.cap_sub + idx;
+    if constexpr (REGIONAL) {
+        const size_t begin = q.var ? (size_t)ro_load(q.count + (size_t)sub * kCountStride + kLineBegin) : (size_t)sub * q.cap_sub;
+        return (size_t)j * q.plane + begin + idx;
+    } else {
+        return ((size_t)j * (q.sub_mask + 1u) + sub) * q.cap_sub + idx;
+    }
 }
-template <typename R>
+template <typename R, bool REGIONAL = false> RT_DEV uint32_t sub_capacity(const QueueDev<R> &q, uint32_t sub)
+{
+    if constexpr (REGIONAL) {
+        if (q.var) return ro_load(q.count + (size_t)sub * kCountStride + kLineCap);
+    }
+    return q.cap_sub;
+}
+template <typename R, bool REGIONAL = false>
 RT_DEV void queue_store(const QueueDev<R> &q, uint32_t sub, uint32_t idx, V3<R> o, V3<R> d, R weight, uint32_t pixel)
 {
-    if (idx < q.cap_sub) {
+    if (idx < sub_capacity<R, REGIONAL>(q, sub)) {
         const R v[8] = { o.x, o.y, o.z, d.x, d.y, d.z, weight, pixel_bits_store<R>(pixel) };
         QueueChunk c[kEntryChunks<R>];
         __builtin_memcpy(c, v, sizeof v);
         QueueChunk *dst = reinterpret_cast<QueueChunk *>(q.rec);
-        for (uint32_t j = 0; j < kEntryChunks<R>; ++j) dst[chunk_index(q, j, sub, idx)] = c[j];
+        for (uint32_t j = 0; j < kEntryChunks<R>; ++j) dst[chunk_index<R, REGIONAL>(q, j, sub, idx)] = c[j];
     } else {
         // cannot happen (queues are sized for the worst case); if it does the ray is dropped and
         // the host reports the frame as failed
@@ -108,8 +122,8 @@ RT_DEV void queue_push_region(const QueueDev<R> &q, uint32_t region, uint32_t ki
     const uint32_t base1 = (uint32_t)__shfl((int)got, (int)la);
     const uint32_t base2 = lb != la ? got2 : (uint32_t)__shfl((int)got2, (int)la);
     const unsigned long long below = (1ull << lane) - 1ull;
-    if (has1) queue_store(q, sub1, base1 + (uint32_t)__popcll(m1 & below), o1, d1, w1, pixel);
-    if (has2) queue_store(q, sub2, base2 + (uint32_t)__popcll(m2 & below), o2, d2, w2, pixel);
+    if (has1) queue_store<R, true>(q, sub1, base1 + (uint32_t)__popcll(m1 & below), o1, d1, w1, pixel);
+    if (has2) queue_store<R, true>(q, sub2, base2 + (uint32_t)__popcll(m2 & below), o2, d2, w2, pixel);
 }
 
 // Count the shaded hits of this wave: one atomic per wave that has any, spread over shards.

@@ -84,19 +84,21 @@ constexpr uint32_t layout_kinds(uint32_t scene_sf) { return child_kinds(sf_varia
 constexpr bool regional_levels(uint32_t sf) { return (sf & SF_CULL) == 0 && (sf & (SF_REFLECTIVE | SF_TRANSPARENT)) != 0; }
 // bytes of a buffer that holds a queue of n_sub sub-queues of cap_sub entries (a multiple of 256: the next buffer
 // starts behind it); behind the rays of a regional queue lies its block list
-template <typename R> inline uint64_t queue_buffer_bytes(uint32_t sf, uint64_t cap_sub, uint32_t n_sub)
+template <typename R> inline uint64_t queue_buffer_bytes(uint32_t sf, uint64_t entries, uint32_t n_sub)
 {
-    const uint64_t entries = cap_sub * n_sub;
     uint64_t b = entries * 8 * sizeof(R);
     if (regional_levels(sf)) b += (entries / kListBlock + n_sub + 1u) * 8u;  // every sub-queue ends with at most one partial block
     return (b + 255u) & ~(uint64_t)255u;
 }
-template <typename R> inline void queue_list_plane(uint32_t sf, QueueDev<R> &q)
+// `entries`: of all sub-queues together (n_sub * cap_sub, or what a queue sized from measured lengths holds)
+template <typename R> inline void queue_list_plane(uint32_t sf, QueueDev<R> &q, uint64_t entries, bool var = false)
 {
     q.list = nullptr;
     q.n_list = nullptr;
+    q.plane = (uint32_t)entries;
+    q.var = var ? 1u : 0u;
     if (regional_levels(sf) && q.rec) {
-        q.list = reinterpret_cast<typename QueueDev<R>::Block *>(q.rec + (uint64_t)q.cap_sub * (q.sub_mask + 1u) * 8);
+        q.list = reinterpret_cast<typename QueueDev<R>::Block *>(q.rec + entries * 8);
         q.n_list = q.count + 2;  // a spare word of the first sub-queue's counter line
     }
 }
@@ -196,12 +198,14 @@ hipError_t scratch_address(void **ptr, size_t *bytes);
 // sub-queue lengths into host memory the device can write, then a sequence number (scratch.hip)
 hipError_t launch_publish_counts(hipStream_t stream, const uint32_t *counts, uint32_t n_sub, uint32_t stride, uint32_t *host, uint32_t seq);
 
-// the block list of a regional queue (scratch.hip); nothing to do for other queues
-hipError_t list_blocks_launch(hipStream_t stream, const uint32_t *count, uint32_t n_sub, uint32_t cap_sub, void *list, uint32_t *n_list);
-template <typename R> inline hipError_t launch_list_blocks(hipStream_t stream, const QueueDev<R> &q)
+// the block list of a regional queue (scratch.hip); nothing to do for other queues.  next_lines: the counter lines
+// of the queue of the level after, when that queue will be sized from this one's lengths (k_list_blocks)
+hipError_t list_blocks_launch(hipStream_t stream, const uint32_t *count, uint32_t n_sub, uint32_t cap_sub, uint32_t var, void *list,
+                              uint32_t *n_list, uint32_t *next_lines, uint32_t kinds);
+template <typename R> inline hipError_t launch_list_blocks(hipStream_t stream, uint32_t sf, const QueueDev<R> &q, uint32_t *next_lines = nullptr)
 {
     if (!q.list || q.cap_sub == 0u) return hipSuccess;
-    return list_blocks_launch(stream, q.count, q.sub_mask + 1u, q.cap_sub, q.list, q.n_list);
+    return list_blocks_launch(stream, q.count, q.sub_mask + 1u, q.cap_sub, q.var, q.list, q.n_list, next_lines, layout_kinds(sf));
 }
 
 // f64 only: intermediate results of one color_at node per ray.

@@ -253,7 +253,15 @@ struct QueueDev {
     struct Block { uint32_t sub, block; };
     Block *list;
     uint32_t *n_list;
+    // Regional queues only.  plane: entries of all sub-queues together (what lies between two planes of the
+    // layout).  var != 0: the queue was sized from the measured lengths of the level before; its sub-queues
+    // differ in capacity (cap_sub is the largest) and lie back to back: sub-queue q begins at entry
+    // count[q * kCountStride + kLineBegin] and holds at most count[q * kCountStride + kLineCap] entries
+    // (written by k_list_blocks when it lists the level before).  var == 0: sub-queue q begins at q * cap_sub.
+    uint32_t plane;
+    uint32_t var;
 };
+constexpr uint32_t kLineBegin = 3, kLineCap = 4;  // words of a sub-queue's counter line (0: length, 1: ticket, 2: n_list in line 0)
 constexpr uint32_t kListBlock = 256;   // entries per block of the list (= threads of the consuming workgroup)
 constexpr uint32_t kListMaxSub = 512;  // most sub-queues of such a queue (256 screen regions of a scene that reflects and refracts;
                                        // 128 to 1024 regions measured alike on a 3840x2160 frame)

@@ -860,7 +860,7 @@ void size_queues(uint32_t sf, uint32_t levels, uint32_t hsize, uint64_t units, F
     for (uint32_t L = 1; L <= levels; ++L) {
         p->cap_sub[L] = cap;
         uint64_t &tot = (L & 1) ? p->odd_bytes : p->even_bytes;
-        tot = std::max(tot, queue_buffer_bytes<R>(sf, cap, n_sub));
+        tot = std::max(tot, queue_buffer_bytes<R>(sf, cap * n_sub, n_sub));
         if (regional) {
             cap *= kinds;
         } else {
@@ -938,6 +938,11 @@ int enqueue_measured_levels(rtx_context *ctx, const rtx_scene *scene, Workspace 
     uint64_t cap_in = plan.cap_sub[1];
     const bool tree = (scene->sf & SF_LANE_TREE) != 0;
     std::vector<uint64_t> feed(n_sub);
+    // Regional queues: the level-1 queue has n_sub sub-queues of one capacity; every deeper queue is laid out by
+    // k_list_blocks from the lengths of the queue before it (sub-queues back to back, each with room for what its
+    // region holds), and holds `kinds` times the rays of that queue.
+    uint64_t entries_in = cap_in * n_sub, entries_out = 0;
+    bool var_in = false;
     for (uint32_t L = 1; L <= max_depth; ++L) {
         uint32_t *level_counts = counts + (size_t)L * n_sub * kCountStride;
         // A one-workgroup kernel behind the level's producer writes the lengths into mapped host memory and
@@ -955,7 +960,7 @@ int enqueue_measured_levels(rtx_context *ctx, const rtx_scene *scene, Workspace 
                 if (q != hipErrorNotReady) return fail(RTX_ERR_DEVICE, "waiting for level %u: %s", L, hipGetErrorString(q));
             }
         }
-        uint64_t longest = 0, cap_out = 0, running_region = 0, cap_region = 0;
+        uint64_t longest = 0, cap_out = 0, running_region = 0, cap_region = 0, rays_in = 0;
         // feed[s]: rays the blocks that send to output sub-queue s hold.  Sub-queue y sends its block b
         // to (b + y) mod n_sub: every full turn of n_sub blocks adds a block to each s, the blocks
         // left over go to a run of sub-queues that starts at y (kept as differences, summed below).
@@ -975,6 +980,7 @@ int enqueue_measured_levels(rtx_context *ctx, const rtx_scene *scene, Workspace 
         for (uint32_t y = 0; y < n_sub; ++y) {
             const uint64_t n = std::min<uint64_t>(ws.host_counts[1 + y], cap_in);
             longest = std::max(longest, n);
+            rays_in += n;
             if (regional) {  // what the sub-queues of this one's region hold together
                 if (y % layout_kinds(scene->sf) == 0) running_region = 0;
                 running_region += n;
@@ -998,10 +1004,11 @@ int enqueue_measured_levels(rtx_context *ctx, const rtx_scene *scene, Workspace 
         if (L < max_depth) {
             for (uint64_t f : feed) cap_out = std::max(cap_out, f);
             if (regional) cap_out = cap_region;
-            if (cap_out > 0x7fffff00ull) return fail(RTX_ERR_INVALID, "level %u of this frame has too many rays for one launch; render fewer rows per call", L + 1);
+            entries_out = regional ? rays_in * layout_kinds(scene->sf) : cap_out * n_sub;
+            if (cap_out > 0x7fffff00ull || entries_out > 0xffffff00ull) return fail(RTX_ERR_INVALID, "level %u of this frame has too many rays for one launch; render fewer rows per call", L + 1);
             void **buf = ((L + 1) & 1) ? &ws.queues : &ws.queues_even;
             size_t *have = ((L + 1) & 1) ? &ws.queue_bytes : &ws.queue_even_bytes;
-            const size_t need = (size_t)queue_buffer_bytes<R>(scene->sf, cap_out, n_sub);
+            const size_t need = (size_t)queue_buffer_bytes<R>(scene->sf, entries_out, n_sub);
             if (need > *have) {
                 // the buffer holds the queue this level's input was made from: nothing reads it any more
                 if (*buf) HIP_TRY(hipFree(*buf));
@@ -1020,24 +1027,28 @@ int enqueue_measured_levels(rtx_context *ctx, const rtx_scene *scene, Workspace 
                 *have = need;
             }
         }
-        auto queue_of = [&](uint32_t level, uint64_t cap) {
+        auto queue_of = [&](uint32_t level, uint64_t cap, uint64_t entries, bool var) {
             QueueDev<R> q;
             q.rec = (R *)((level & 1) ? ws.queues : ws.queues_even);
             q.count = counts + (size_t)level * n_sub * kCountStride;
             q.cap_sub = (uint32_t)cap;
             q.sub_mask = n_sub - 1;
             q.overflow = ctx->overflow_dev;
-            queue_list_plane<R>(scene->sf, q);
+            queue_list_plane<R>(scene->sf, q, entries, var);
             return q;
         };
         // the launch covers the longest sub-queue that exists, not the capacity
-        QueueDev<R> in_q = queue_of(L, cap_in);
-        const QueueDev<R> out_q = queue_of(L + 1, L < max_depth ? cap_out : 0);
+        QueueDev<R> in_q = queue_of(L, cap_in, entries_in, var_in);
+        const QueueDev<R> out_q = L < max_depth ? queue_of(L + 1, cap_out, entries_out, regional) : queue_of(L + 1, 0, 0, false);
         HIP_TRY(launch_bounce<R>(scene->sf, stream, scene_dev<R>(scene), in_q, out_q, max_depth - L, L, fb,
                                  ws.shards, tree ? ctx->bounce_blocks_lane : ctx->bounce_blocks, (uint32_t)longest));
         ++*launches;
-        if (L < max_depth) HIP_TRY(launch_list_blocks<R>(stream, out_q));
+        // (the list of the next queue, and with it the layout of the queue after that)
+        if (L < max_depth)
+            HIP_TRY(launch_list_blocks<R>(stream, scene->sf, out_q, L + 1 < max_depth ? counts + (size_t)(L + 2) * n_sub * kCountStride : nullptr));
         cap_in = cap_out;
+        entries_in = entries_out;
+        var_in = regional;
     }
     return RTX_OK;
 }
@@ -1214,7 +1225,7 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Workspace &ws, hipEv
             q.cap_sub = level <= plan.levels ? (uint32_t)plan.cap_sub[level] : 0u;
             q.sub_mask = plan.n_sub - 1;
             q.overflow = ctx->overflow_dev;
-            queue_list_plane<R>(scene->sf, q);
+            queue_list_plane<R>(scene->sf, q, (uint64_t)q.cap_sub * plan.n_sub);
             return q;
         };
         const uint64_t k0 = cam ? u0 * W : u0;  // first primary ray of the chunk
@@ -1230,7 +1241,10 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Workspace &ws, hipEv
         }
         if (timed && c == 0) HIP_TRY(hipEventRecord(ev[3], stream));
         ++launches;
-        if (plan.levels >= 1u) HIP_TRY(launch_list_blocks<R>(stream, queue_at(1)));
+        // (a measured frame lays out its second queue from the lengths of the first)
+        if (plan.levels >= 1u)
+            HIP_TRY(launch_list_blocks<R>(stream, scene->sf, queue_at(1),
+                                          measured && max_depth >= 2 ? counts + (size_t)2 * plan.n_sub * kCountStride : nullptr));
         if (measured) {
             rc = enqueue_measured_levels<R>(ctx, scene, ws, stream, plan, counts, max_depth, fb, &launches);
             if (rc) return rc;
@@ -1245,7 +1259,7 @@ int enqueue_frame(rtx_context *ctx, const rtx_scene *scene, Workspace &ws, hipEv
                                                                 : (scene->sf & SF_CULL) ? ctx->bounce_blocks_cull : ctx->bounce_blocks,
                                      0u));
             ++launches;
-            if (L < plan.levels) HIP_TRY(launch_list_blocks<R>(stream, queue_at(L + 1)));
+            if (L < plan.levels) HIP_TRY(launch_list_blocks<R>(stream, scene->sf, queue_at(L + 1)));
         }
         done += cam ? units * W : units;
         if (progress) {
