@@ -122,7 +122,9 @@ typedef struct rtx_stats {
     double kernel_ms;         /* device time of the render kernels (HIP events on the call's stream) */
     double primary_kernel_ms; /* device time of the primary-ray kernel alone */
     double total_ms;          /* host wall time of the call, copies included */
-    uint32_t n_launches;      /* kernels launched */
+    uint32_t n_launches;      /* launches that trace rays: the primary-ray kernel of every row chunk and one per recursion
+                                 level of it (the small kernels between them, k_frame_begin, k_list_blocks and
+                                 k_publish_counts, are not counted) */
     uint32_t n_chunks;        /* row chunks the frame was split into to bound queue memory */
     double levels_ms;         /* device time from the end of the first chunk's primary-ray kernel to the end of the
                                  frame's kernels: for a frame of one chunk, its recursion levels (one launch each) */
@@ -153,7 +155,7 @@ int rtx_context_set_debug_queue_divisor(rtx_context *ctx, uint32_t divisor);
 int rtx_context_set_workspace_limit(rtx_context *ctx, size_t bytes);
 /* Secondary-ray queues are sized on the host for the worst case, which doubles with every level in
  * a scene that both reflects and refracts (World::reflected_color and World::refracted_color,
- * src/scenes/world.rs:160-190, both recurse): about 26 GB for a 4K frame of depth 5 whose rays
+ * src/scenes/world.rs:160-190, both recurse): about 27 GB for a 4K frame of depth 5 whose rays
  * would fit 2 GB.  A call that returns a finished frame (no stream of the caller's, or host
  * output, or stats) and whose worst case exceeds `worst_case_bytes_above` reads the lengths of
  * each level's queues back before launching it and sizes the next level for what those rays can
