@@ -53,8 +53,8 @@ RT_DEV void entry_take(const QueueChunk *lds, uint32_t stride, uint32_t wave, ui
     if (want) {
         // The transfers memory -> LDS count as vector memory operations: all of them have landed when
         // that counter is zero.  Stated here and not left to the compiler, which orders an LDS read after
-        // such a transfer only where it can see that the two may touch the same bytes (it read two of the
-        // four chunks early once the sort above used the same array).
+        // such a transfer only where it can see that the two may touch the same bytes (with other LDS traffic
+        // to the same array in between it has read two of the four chunks early).
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         QueueChunk c[kEntryChunks<R>];
         for (uint32_t j = 0; j < kEntryChunks<R>; ++j) c[j] = lds[(wave * stride + j) * 64u + lane];
@@ -65,85 +65,6 @@ RT_DEV void entry_take(const QueueChunk *lds, uint32_t stride, uint32_t wave, ui
         weight = v[6];
         pixel = pixel_bits_load<R>(v[7]);
     }
-}
-
-// ---- regrouping the rays of a workgroup by the object they hit --------------------------------
-// The rays a wave takes from the queue have little to do with each other: after the closest-hit
-// walk its 64 lanes hold hits on half a dozen different objects (or none), and what follows --
-// normal by shape, pattern by type, reflection / refraction / Schlick by material, the specular
-// power, the shadow ray from that object's surface -- runs branch by branch with a few lanes
-// each.  Between the two phases the workgroup therefore sorts its rays by hit object: a counting
-// sort in LDS (one LDS atomic per ray for its rank within its bin, a 64-bin prefix sum per wave,
-// the ray and its hit written to their place and read back by the thread that owns that place).
-// Afterwards the lanes of a wave hold hits on the same object (two, where a wave straddles a bin
-// boundary), rays that hit nothing fill waves of their own at the end and skip the rest, and the
-// child rays are appended to the next queue in that order, so that the next level's waves start
-// from rays that left the same object.  Nothing else changes: the same rays, the same arithmetic
-// per ray, another thread.
-//
-// The sorted rays pass through the same LDS the queue entries are prefetched into: place p of the
-// sort is chunk slice p / 64, lane p % 64, and a wave's own places are its own slice.  A wave asks
-// for its next entries once it has read its places back; they arrive while it shades, and it takes
-// them before the next sort's barrier, after which any wave may write into the slice again.
-constexpr uint32_t kSortBins = 64;
-// chunks per wave slice: the entry's (origin, direction, weight, and t in place of the pixel word),
-// then {pixel, slot, object << 1 | holds a ray, hit_open}, then for scenes with transparency {top1, top2}
-template <typename R, bool SORT, bool TRACK> constexpr uint32_t kSliceChunks = kEntryChunks<R> + (SORT ? (TRACK ? 2u : 1u) : 0u);
-// Every thread of the workgroup calls this; `hist`: 2 x kSortBins counters, zero on the first
-// call, of which the calls use one and clear the other in turn (`round`).
-template <typename R, bool TRACK>
-RT_DEV void sort_by_hit_object(QueueChunk *lds, uint32_t *hist2, uint32_t round, bool &valid, V3<R> &ro, V3<R> &rd, R &weight,
-                               uint32_t &pixel, Hit<R> &h)
-{
-    constexpr uint32_t kStride = kSliceChunks<R, true, TRACK>, kE = kEntryChunks<R>;
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    uint32_t *hist = hist2 + (round & 1u) * kSortBins, *other = hist2 + ((round & 1u) ^ 1u) * kSortBins;
-    // bin: the object's index in World.objects (scenes handled here have few objects; indices past the
-    // bins share one), then the rays without a hit, then the lanes without a ray
-    const uint32_t key = !valid ? kSortBins - 1u : h.slot == kNone ? kSortBins - 2u : (h.obj < kSortBins - 3u ? h.obj : kSortBins - 3u);
-    const uint32_t rank = atomicAdd(&hist[key], 1u);
-    __syncthreads();
-    if (threadIdx.x < kSortBins) other[threadIdx.x] = 0u;  // for the next call: nobody reads it any more, nobody adds to it yet
-    // exclusive prefix sum over the bins, by every wave for itself
-    const uint32_t mine = hist[lane];
-    uint32_t incl = mine;
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t up = __shfl_up(incl, off);
-        if ((int)lane >= off) incl += up;
-    }
-    const uint32_t at = __shfl(incl - mine, (int)key) + rank;
-    QueueChunk *dst = lds + (at >> 6) * kStride * 64u + (at & 63u);
-    {
-        const R v[8] = { ro.x, ro.y, ro.z, rd.x, rd.y, rd.z, weight, h.t };
-        QueueChunk c[kE];
-        __builtin_memcpy(c, v, sizeof v);
-        for (uint32_t j = 0; j < kE; ++j) dst[j * 64u] = c[j];
-        dst[kE * 64u] = QueueChunk{ { pixel, h.slot, (h.obj << 1) | (valid ? 1u : 0u), h.hit_open ? 1u : 0u } };
-        if constexpr (TRACK) dst[(kE + 1u) * 64u] = QueueChunk{ { h.top1, h.top2, 0u, 0u } };
-    }
-    __syncthreads();
-    const QueueChunk *src = lds + wave * kStride * 64u + lane;
-    QueueChunk c[kE];
-    for (uint32_t j = 0; j < kE; ++j) c[j] = src[j * 64u];
-    R v[8];
-    __builtin_memcpy(v, c, sizeof v);
-    ro = { v[0], v[1], v[2] };
-    rd = { v[3], v[4], v[5] };
-    weight = v[6];
-    h.t = v[7];
-    const QueueChunk tags = src[kE * 64u];
-    pixel = tags.w[0];
-    h.slot = tags.w[1];
-    valid = (tags.w[2] & 1u) != 0u;
-    h.obj = h.slot == kNone ? kNone : tags.w[2] >> 1;
-    h.hit_open = tags.w[3] != 0u;
-    if constexpr (TRACK) {
-        const QueueChunk tops = src[(kE + 1u) * 64u];
-        h.top1 = tops.w[0];
-        h.top2 = tops.w[1];
-    }
-    // what this wave read is in its registers before anything else may be written into its slice
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
 // The loop's trip count is unknown to the compiler, which would otherwise move the literal
@@ -158,11 +79,10 @@ RT_DEV void sort_by_hit_object(QueueChunk *lds, uint32_t *hist2, uint32_t round,
 //   1. ask for the entries of the block after this one (memory -> LDS, nothing waits) and for the list item of
 //      the block after that;
 //   2. closest hit of this block's rays;
-//   3. (f32) the workgroup's rays regrouped by hit object;
-//   4. the child rays, appended to the next level's queue at once (one instruction reserves the places of both
+//   3. the child rays, appended to the next level's queue at once (one instruction reserves the places of both
 //      kinds), which frees their registers for the shadow ray, whose walk covers the latency of
 //      the stores; shadow ray and lighting;
-//   5. take the next block's entries from LDS (they arrived long ago), then add this block's
+//   4. take the next block's entries from LDS (they arrived long ago), then add this block's
 //      weight * lighting to the framebuffer: the atomics are in flight while the next round
 //      computes.
 // COLD_LDS: the launch comes with cold_lds_bytes() of dynamic LDS and the scene has at most
@@ -174,25 +94,12 @@ k_bounce_regional(BounceArgs<R> args_in_kernarg_segment)
     static_assert(regional_levels(SF) && bounce_block<R>(SF) == kListBlock, "a block of the list is a workgroup's piece");
     constexpr uint32_t kPiece = kListBlock;
     constexpr uint32_t kKinds = child_kinds(SF);
-    // The rays of a workgroup are regrouped by hit object between the two phases -- in f32.  Measured on a 4K
-    // frame of an 8-object scene with glass: 46 instead of 42 of 64 lanes active per vector instruction and 3 %
-    // fewer vector instructions in either precision, which the two barriers per round give back in f64 (1.84
-    // against 1.82 ms; rounds are twice as long there and the waves of a workgroup drift further apart) and do
-    // not in f32 (1.165 against 1.185 ms).
-    constexpr bool kSort = bounce_regroups<R>();
-    constexpr bool kTrack = (SF & SF_TRANSPARENT) != 0;
-    constexpr uint32_t kStride = kSliceChunks<R, kSort, kTrack>;
+    constexpr uint32_t kStride = kEntryChunks<R>;
     __shared__ QueueChunk lds[(kPiece / 64u) * kStride * 64u];
-    __shared__ uint32_t sort_hist[kSort ? 2u * kSortBins : 1u];
     const RT_CONSTANT_AS BounceArgs<R> *kp =
         (const RT_CONSTANT_AS BounceArgs<R> *)__builtin_amdgcn_kernarg_segment_ptr();
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    if constexpr (kSort) {
-        for (uint32_t i = threadIdx.x; i < 2u * kSortBins; i += kPiece) sort_hist[i] = 0u;
-        if constexpr (!COLD_LDS) __syncthreads();
-    }
     if constexpr (COLD_LDS) stage_cold_table<R>(args_in_kernarg_segment.S, kPiece);  // ends with a barrier
-    uint32_t round = 0;
     V3<R> ro = { R(0), R(0), R(0) }, rd = ro;
     R weight = R(0);
     uint32_t pixel = 0;
@@ -235,7 +142,7 @@ k_bounce_regional(BounceArgs<R> args_in_kernarg_segment)
         const bool more = ticket + gridDim.x < n_list;  // wave-uniform
         uint32_t k_next = 0;
         const bool valid_next = more && holds(A.in_q, item1, k_next);
-        if constexpr (!kSort) entry_prefetch<R, true>(lds, kStride, wave, valid_next, A.in_q, item1.sub, k_next);
+        entry_prefetch<R, true>(lds, kStride, wave, valid_next, A.in_q, item1.sub, k_next);
         at_list = after(at_list);
         Block item2 = item1;
         if (ticket + 2u * gridDim.x < n_list) item2 = load_uniform(A.in_q.list + at_list);
@@ -244,30 +151,17 @@ k_bounce_regional(BounceArgs<R> args_in_kernarg_segment)
         nd.hit = false;
         nd.has_reflect = nd.has_refract = false;
         nd.lighting = { R(0), R(0), R(0) };
-        R w = weight;
-        uint32_t px_index = pixel;
-        bool live = valid;  // this thread holds a ray in the second phase (after regrouping: not the one it loaded)
-        auto push_children = [&](const Node<R> &c) {
-            queue_push_region(A.out_q, region, kKinds, c.has_reflect, c.over_point, c.reflectv, w * c.reflect_factor, c.has_refract,
-                              c.under_point, c.refract_dir, w * c.refract_factor, px_index);
-        };
-        if constexpr (kSort) {
-            Hit<R> h;
-            h.t = Num<R>::inf;
-            h.slot = h.obj = kNone;
-            h.hit_open = false;
-            h.top1 = h.top2 = kNone;
-            h.top1_t = h.top2_t = -Num<R>::inf;
-            if (valid) h = closest_hit<R, kTrack, false, (SF & SF_CHAIN) != 0, WALK_WAVE, COLD_LDS>(A.S, ro, rd, Num<R>::inf);
-            sort_by_hit_object<R, kTrack>(lds, sort_hist, round++, live, ro, rd, w, px_index, h);
-            entry_prefetch<R, true>(lds, kStride, wave, valid_next, A.in_q, item1.sub, k_next);
-            if (live) nd = shade_node<R, SF, false, WALK_WAVE, COLD_LDS>(A.S, ro, rd, A.remaining, h, push_children);
-        } else if (valid) {
-            nd = trace_node<R, SF, false, WALK_WAVE, COLD_LDS>(A.S, nullptr, ro, rd, A.remaining, push_children);
+        const R w = weight;
+        const uint32_t px_index = pixel;
+        if (valid) {
+            nd = trace_node<R, SF, false, WALK_WAVE, COLD_LDS>(A.S, nullptr, ro, rd, A.remaining, [&](const Node<R> &c) {
+                queue_push_region(A.out_q, region, kKinds, c.has_reflect, c.over_point, c.reflectv, w * c.reflect_factor, c.has_refract,
+                                  c.under_point, c.refract_dir, w * c.refract_factor, px_index);
+            });
         }
-        count_hits(A.stats, ticket, A.level, live && nd.hit);
+        count_hits(A.stats, ticket, A.level, valid && nd.hit);
         entry_take<R>(lds, kStride, wave, lane, valid_next, ro, rd, weight, pixel);
-        if (live && nd.hit) {
+        if (valid && nd.hit) {
             R *px = A.fb + (size_t)px_index * 3;
             fb_add<R>(px + 0, nd.lighting.x * w);
             fb_add<R>(px + 1, nd.lighting.y * w);
@@ -295,7 +189,7 @@ k_bounce(BounceArgs<R> args_in_kernarg_segment)
 {
     static_assert((SF & SF_CULL) != 0, "scenes with the sphere hierarchy");
     constexpr uint32_t kPiece = bounce_block<R>(SF);  // rays per piece = threads per workgroup
-    constexpr uint32_t kStride = kSliceChunks<R, false, false>;
+    constexpr uint32_t kStride = kEntryChunks<R>;
     __shared__ QueueChunk lds[(kPiece / 64u) * kStride * 64u];
     const RT_CONSTANT_AS BounceArgs<R> *kp =
         (const RT_CONSTANT_AS BounceArgs<R> *)__builtin_amdgcn_kernarg_segment_ptr();

@@ -26,8 +26,6 @@ template <typename R> constexpr uint32_t bounce_block(uint32_t sf)
     if (sf & SF_LANE_TREE) return kLaneTreeBlock;
     return sizeof(R) == 8 ? ((sf & SF_CULL) ? 128u : 256u) : 256u;
 }
-// whether the bounce kernel of regional levels regroups a workgroup's rays by hit object between walk and shading
-template <typename R> constexpr bool bounce_regroups() { return sizeof(R) == 4; }
 // Lane slots per block index of a bounce launch: the children of block b of sub-queue y go to sub-queue
 // (b + y) mod n_sub, whatever workgroup or wave traces them, which is what bounds the next level's sub-queues.
 // A block is a workgroup's piece, except in the kernel that hands its rays out a wave at a time: there a block
