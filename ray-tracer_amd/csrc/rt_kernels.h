@@ -4,10 +4,11 @@
 //   k_primary  one pixel per lane: ray_for_pixel -> closest hit over the object table ->
 //              shadow ray -> Phong; stores the pixel's own lighting term and appends the
 //              reflection / refraction rays it spawns to the level-1 queue.
-//   k_bounce   one queued ray per lane, same work; adds weight * lighting to its pixel and
+//   k_bounce_regional / k_bounce / k_bounce_tree (rt_bounce.h, by the kind of scene)
+//              one queued ray per lane, same work; adds weight * lighting to its pixel and
 //              appends to the next level's queue.  Launched once per recursion level.
-// Queue appends are aggregated per wave: one atomic per 64-lane wave reserves a contiguous
-// run of slots, each lane writes its slot with 16-byte stores.
+// Queue appends are aggregated per wave: one atomic instruction per 64-lane wave reserves contiguous
+// runs of slots, each lane writes its slot with 16-byte stores.
 #pragma once
 
 #include "rt_device.h"

@@ -26,8 +26,9 @@ template <typename R> constexpr uint32_t bounce_block(uint32_t sf)
     if (sf & SF_LANE_TREE) return kLaneTreeBlock;
     return sizeof(R) == 8 ? ((sf & SF_CULL) ? 128u : 256u) : 256u;
 }
-// Lane slots per block index of a bounce launch: the children of block b of sub-queue y go to sub-queue
-// (b + y) mod n_sub, whatever workgroup or wave traces them, which is what bounds the next level's sub-queues.
+// Lane slots per block index of a bounce launch of a scene with the sphere hierarchy: the children of block b of
+// sub-queue y go to sub-queue (b + y) mod n_sub, whatever workgroup or wave traces them, which is what bounds the
+// next level's sub-queues.
 // A block is a workgroup's piece, except in the kernel that hands its rays out a wave at a time: there a block
 // is what one wave takes, so that the rays of a long sub-queue, and in a short level every single ray, spread
 // over as many sub-queues of the next level (deep levels come from few pixels; with blocks of 1024 the few
@@ -177,8 +178,9 @@ struct Launch {
 };
 
 // One recursion level below the primary rays: consume in_q, add weight * lighting into fb, queue
-// the next level.  The launch has about resident_blocks workgroups (what the chip holds at
-// once), shared out evenly among the sub-queues; they loop over the rays that exist.  `longest`:
+// the next level.  The launch has about resident_blocks workgroups (several times what the chip holds at
+// once), shared out evenly among the sub-queues, or sharing the queue's block list in a scene with regional
+// levels; they loop over the rays that exist.  `longest`:
 // the length of the longest input sub-queue when the caller knows it (0: only its capacity is known).
 template <typename R>
 hipError_t launch_bounce(uint32_t sf, hipStream_t stream, const SceneDev<R> &scene, const QueueDev<R> &in_q,

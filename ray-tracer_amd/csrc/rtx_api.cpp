@@ -920,8 +920,10 @@ int check_overflow(rtx_context *ctx)
 // entries per sub-queue) has been filled by the primary launch already queued on `stream`.  Before
 // each level the lengths of its sub-queues are read back; block b of sub-queue y (bounce_block rays,
 // the last one fewer) sends its children to sub-queue (b + y) mod n_sub of the next queue
-// (k_bounce), which is therefore sized for the largest sum of such blocks times the children a ray
-// can have.  A level without rays ends the chunk.
+// (k_bounce, k_bounce_tree), which is therefore sized for the largest sum of such blocks times the children a ray
+// can have; in a scene with regional levels the children stay in the sub-queues of their region, and the next
+// queue gets room for twice the rays of this one, sub-queue by sub-queue (k_list_blocks lays it out).  A level
+// without rays ends the chunk.
 template <typename R>
 int enqueue_measured_levels(rtx_context *ctx, const rtx_scene *scene, Workspace &ws, hipStream_t stream, const FramePlan &plan,
                             uint32_t *counts, uint32_t max_depth, R *fb, uint32_t *launches)
