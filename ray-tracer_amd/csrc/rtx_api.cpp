@@ -889,6 +889,8 @@ int plan_frame(size_t limit, uint32_t sf, uint32_t max_depth, uint32_t hsize, ui
         if (p->bytes > limit) return false;
         for (uint32_t L = 1; L <= levels; ++L)
             if (p->cap_sub[L] > 0x7fffff00ull) return false;  // sub-queue slots are indexed with 32 bits
+        for (uint32_t L = 1; L <= levels; ++L)
+            if (regional_levels(sf) && p->cap_sub[L] * p->n_sub > 0xffffff00ull) return false;  // and so are the entries of a regional queue
         return true;
     };
     uint64_t hi = std::min<uint64_t>(std::max<uint64_t>(n_units, 1), max_units);
